@@ -1,0 +1,315 @@
+/*
+ * ptgpu.h -- C ABI of the MI355X render path for PathTracerRust.
+ *
+ * The reference crate has no FFI layer; this header is the seam a Rust
+ * `extern "C"` block (linked by build.rs against libptgpu.so) binds.  Every
+ * entry point names the reference interface it stands in for (file:line under
+ * the reference crate's root).
+ *
+ * Conventions
+ *   - plain-old-data only: int32/uint32/uint64/double/float, no C++ types;
+ *   - every input pointer is borrowed for the duration of the call;
+ *   - every function returns PT_OK (0) or a negative pt_status, never throws;
+ *   - one caller thread per pt_ctx (the reference has a single dispatcher
+ *     thread, src/lib.rs:407-478);
+ *   - geometry travels as f64, the reference's arithmetic type
+ *     (src/math/vec3.rs:4-8).
+ *
+ * The scene travels as a serialised copy of the reference's object graph
+ * (`Arc<dyn Hitable>` tree, src/hitable.rs:27-36): one pt_hitable per node,
+ * children by index.  The library flattens that graph into its device layout
+ * on upload; a CPU oracle can interpret the same graph directly.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = -1,
+    PT_ERR_UNSUPPORTED_SCENE = -2, /* graph shape the device flattener does not take */
+    PT_ERR_NO_DEVICE = -3,
+    PT_ERR_HIP = -4,          /* a HIP runtime call failed; see pt_last_error */
+    PT_ERR_NO_SCENE = -5,
+    PT_ERR_NO_CAMERA = -6,
+    PT_ERR_OUT_OF_MEMORY = -7,
+    PT_ERR_TOO_LARGE = -8
+} pt_status;
+
+/* ------------------------------------------------------------------------ */
+/* Scene graph wire format                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* One node of the Hitable graph (src/hitable.rs:27-36 and its implementors). */
+typedef enum pt_hitable_kind {
+    PT_H_SPHERE = 1,        /* src/sphere.rs:27-41     f: center xyz, radius */
+    PT_H_MOVING_SPHERE = 2, /* src/sphere.rs:104-133   f: center0 xyz, radius, center_range xyz, time0, time_range */
+    PT_H_RECT = 3,          /* src/rect.rs:13-61       f: amin amax bmin bmax c ; axis */
+    PT_H_BOX = 4,           /* src/axis_aligned_box.rs:14-29  f: pmin xyz, pmax xyz ; list = its 6 face nodes */
+    PT_H_LIST = 5,          /* src/hitable.rs:40-78    list = children in order */
+    PT_H_FLIP = 6,          /* src/hitable.rs:80-105   child[0] */
+    PT_H_TRANSLATE = 7,     /* src/hitable.rs:107-138  child[0] ; f: translation xyz */
+    PT_H_ROTATE_Y = 8,      /* src/hitable.rs:140-216  child[0] ; f: sin, cos, bbox min xyz, bbox max xyz */
+    PT_H_MEDIUM = 9,        /* src/volume.rs:7-22      child[0] = boundary ; f: density ; material = Isotropic phase fn */
+    PT_H_BVH = 10           /* src/bvh.rs:6-10         child[0]=left child[1]=right ; f: bbox min xyz, max xyz */
+} pt_hitable_kind;
+
+typedef struct pt_hitable {
+    int32_t kind;        /* pt_hitable_kind */
+    int32_t material;    /* index into materials, -1 if the node carries none */
+    int32_t child[2];    /* node indices, -1 if unused */
+    int32_t list_start;  /* LIST/BOX: first entry in child_index[] */
+    int32_t list_count;  /* LIST/BOX: number of entries */
+    int32_t axis;        /* RECT: 0 = X, 1 = Y, 2 = Z (src/rect.rs:7-11) */
+    int32_t reserved;
+    double f[10];        /* per-kind parameters, see pt_hitable_kind */
+} pt_hitable;
+
+typedef enum pt_material_kind {
+    PT_M_DUMMY = 0,         /* src/material.rs:152-162 */
+    PT_M_LAMBERTIAN = 1,    /* src/material.rs:253-306  texture, emissive */
+    PT_M_DIFFUSE_LIGHT = 2, /* src/material.rs:308-332  texture */
+    PT_M_METAL = 3,         /* src/material.rs:215-251  albedo, fuzz (already clamped to <= 1) */
+    PT_M_DIELECTRIC = 4,    /* src/material.rs:164-213  ref_idx */
+    PT_M_ISOTROPIC = 5      /* src/material.rs:334-352  texture */
+} pt_material_kind;
+
+typedef struct pt_material {
+    int32_t kind;      /* pt_material_kind */
+    int32_t texture;   /* index into textures, -1 if unused */
+    double albedo[3];  /* METAL */
+    double fuzz;       /* METAL */
+    double ref_idx;    /* DIELECTRIC */
+    double emissive;   /* LAMBERTIAN */
+} pt_material;
+
+typedef enum pt_texture_kind {
+    PT_T_CONSTANT = 0, /* src/texture.rs:12-28   colour */
+    PT_T_CHECKER = 1,  /* src/texture.rs:30-56   even, odd texture indices */
+    PT_T_NOISE = 2,    /* src/texture.rs:58-75   scale */
+    PT_T_IMAGE = 3     /* src/texture.rs:77-114  width, height, texel_offset (RGB8 rows top-down as decoded) */
+} pt_texture_kind;
+
+typedef struct pt_texture {
+    int32_t kind;          /* pt_texture_kind */
+    int32_t even;          /* CHECKER */
+    int32_t odd;           /* CHECKER */
+    int32_t width;         /* IMAGE */
+    int32_t height;        /* IMAGE */
+    int32_t reserved;
+    uint64_t texel_offset; /* IMAGE: byte offset into texels[] */
+    double colour[3];      /* CONSTANT */
+    double scale;          /* NOISE */
+} pt_texture;
+
+/* The four lazily built Perlin tables (src/math/noise.rs:78-83). */
+typedef struct pt_perlin {
+    double ranvec[256][3];
+    int32_t perm_x[256];
+    int32_t perm_y[256];
+    int32_t perm_z[256];
+} pt_perlin;
+
+typedef struct pt_scene_desc {
+    uint32_t struct_size;        /* sizeof(pt_scene_desc) */
+    int32_t root;                /* node the renderer calls hit() on: SceneState.world (src/trace.rs:46) */
+    const pt_hitable *hitables;
+    int32_t n_hitables;
+    int32_t n_child_index;
+    const int32_t *child_index;  /* LIST/BOX children */
+    const pt_material *materials;
+    const pt_texture *textures;
+    int32_t n_materials;
+    int32_t n_textures;
+    const uint8_t *texels;       /* RGB8 blobs of IMAGE textures */
+    uint64_t n_texel_bytes;
+    const pt_perlin *perlin;     /* NULL when no NOISE texture is present */
+    const int32_t *lights;       /* nodes of the light-shape HitableList (src/trace.rs:123-128) */
+    int32_t n_lights;
+    int32_t reserved;
+} pt_scene_desc;
+
+/* The nine Camera::new parameters (src/camera.rs:25-26). */
+typedef struct pt_camera {
+    double origin[3];
+    double look_at[3];
+    double vup[3];
+    double vfov;       /* degrees */
+    double aspect;
+    double aperture;
+    double focus_dist;
+    double time0;
+    double time1;
+} pt_camera;
+
+typedef struct pt_ray {
+    double origin[3];
+    double direction[3]; /* not normalised (src/math/ray.rs:5) */
+    double time;
+} pt_ray;
+
+/* HitRecord (src/hitable.rs:5-12) plus the node that produced it. */
+typedef struct pt_hit {
+    double t;         /* undefined when prim < 0 */
+    double u, v;
+    double p[3];
+    double normal[3];
+    int32_t prim;     /* graph index of the geometry node that was hit (sphere, rect, or medium); -1 = miss */
+    int32_t material; /* index into materials */
+} pt_hit;
+
+/* ------------------------------------------------------------------------ */
+/* Device context                                                            */
+/* ------------------------------------------------------------------------ */
+
+typedef struct pt_ctx pt_ctx;
+
+typedef struct pt_config {
+    uint32_t struct_size;
+    int32_t device;              /* HIP device ordinal */
+    uint64_t seed;               /* master seed of the counter-based RNG */
+    uint32_t max_paths_in_flight;/* paths per wavefront pass; 0 = library default */
+    uint32_t flags;              /* PT_CFG_* */
+} pt_config;
+
+#define PT_CFG_PROFILE_STAGES 1u /* bracket every kernel launch of sampled passes with HIP events */
+#define PT_CFG_COUNT_TRAVERSAL 2u /* count node visits / primitive tests in the extend kernel */
+
+typedef enum pt_render_mode {
+    PT_MODE_OFFLINE = 0,    /* overwrite rgb with the mean of spp samples (src/trace.rs:178-181) */
+    PT_MODE_REALTIME = 1    /* 80 % pixel skip + 1/n running blend capped at 1001 (src/trace.rs:144-177) */
+} pt_render_mode;
+
+typedef struct pt_render_args {
+    uint32_t struct_size;
+    uint32_t width, height;   /* image_size (src/trace.rs:74) */
+    uint32_t x0, y0, x1, y1;  /* start_xy / end_xy of the tile, y counted from the bottom (src/trace.rs:72-73,135-139) */
+    uint32_t spp;             /* num_samples (src/trace.rs:71) */
+    uint32_t max_depth;       /* Config.max_depth (src/lib.rs:109-123) */
+    uint32_t mode;            /* pt_render_mode */
+    uint32_t frame;           /* dispatch number; salts the RNG so successive realtime frames differ */
+    uint32_t reserved;
+} pt_render_args;
+
+typedef struct pt_stats {
+    uint64_t paths;            /* paths traced since the last pt_stats_reset */
+    uint64_t segments;         /* extend invocations (ray segments) */
+    uint64_t node_visits;      /* BVH boxes tested   (needs PT_CFG_COUNT_TRAVERSAL) */
+    uint64_t prim_tests;       /* primitives tested  (needs PT_CFG_COUNT_TRAVERSAL) */
+    uint64_t nan_pixels;       /* pixels whose last written colour has a NaN channel */
+    uint64_t launches_raygen, launches_extend, launches_shade, launches_resolve;
+    double ms_raygen, ms_extend, ms_shade, ms_resolve; /* summed HIP-event time of profiled launches */
+    uint64_t profiled_segments;/* segments processed by the profiled extend/shade launches */
+    uint64_t profiled_paths;   /* paths processed by the profiled raygen/resolve launches */
+    uint64_t profiled_passes;  /* profiled raygen (= resolve) launches */
+    uint64_t profiled_bounce_launches; /* profiled extend (= shade) launches */
+} pt_stats;
+
+/* No reference counterpart (the crate owns no device); allocates the per-GPU state. */
+int pt_create(const pt_config *cfg, pt_ctx **out);
+void pt_destroy(pt_ctx *ctx);
+const char *pt_last_error(pt_ctx *ctx);
+
+/* Replaces handing `world: Box<dyn Hitable>` to SceneState::new (src/trace.rs:55-67, src/lib.rs:359). */
+int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene);
+
+/* Replaces Camera::new (src/camera.rs:25-51); call again after moving the camera (Camera::update, 89-96). */
+int pt_camera_set(pt_ctx *ctx, const pt_camera *cam);
+
+/* Replaces Jobs::dispatch_jobs + wait on one TraceSceneBatchJob::run (src/trace.rs:117-196,
+ * src/lib.rs:396-399,476-478): traces the tile into the context's f32 RGBA image. Synchronous. */
+int pt_render(pt_ctx *ctx, const pt_render_args *args);
+
+/* Replaces TraceSceneBatchJob::clear_buffer + zeroing the image (src/trace.rs:112-115, src/lib.rs:462-468). */
+int pt_accum_reset(pt_ctx *ctx);
+
+/* Replaces reading SceneOutput.buffer (src/lib.rs:496-509): copies width*height*4 floats, row 0 = bottom scanline. */
+int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats);
+
+/* Device address of the f32 RGBA image (for RCCL gathers issued by the host layer); NULL before the first render. */
+void *pt_image_device_ptr(pt_ctx *ctx);
+
+/* Render into caller-owned device memory of width*height*4 floats instead of the context's image. NULL restores it. */
+int pt_image_bind(pt_ctx *ctx, void *device_rgba, uint32_t width, uint32_t height);
+
+/* Replaces Hitable::hit on SceneState.world for a batch (src/hitable.rs:28): closest hit in (t_min, t_max).
+ * `medium_seed` keys the free-flight draw of ConstantMedium::hit (src/volume.rs:42) for ray i. */
+int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double t_max,
+                 uint64_t medium_seed, pt_hit *out);
+
+int pt_stats_get(pt_ctx *ctx, pt_stats *out);
+int pt_stats_reset(pt_ctx *ctx);
+
+/* The HIP stream every kernel of this context is launched on (hipStream_t). */
+void *pt_stream(pt_ctx *ctx);
+
+/* Benchmark form of pt_intersect: rays already resident in device memory (SoA of 7 f64 arrays of length n:
+ * ox oy oz dx dy dz time), hits left on the device; runs `repeats` launches and returns their mean duration. */
+int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double t_min, double t_max,
+                        uint64_t medium_seed, int repeats, double *mean_ms_out);
+
+/* ------------------------------------------------------------------------ */
+/* Host-side scene construction (mirrors SceneBuilder / MaterialBuilder)     */
+/* ------------------------------------------------------------------------ */
+
+typedef struct pt_scene pt_scene; /* owns the arrays a pt_scene_desc points into */
+
+/* Named scene recipes of the reference (src/lib.rs:674-1077) plus the synthetic sphere cloud.
+ * `param` is recipe-specific (sphere count for "sphere_cloud", 1 = book semantics for "cornell_smoke"). */
+int pt_scene_build_named(const char *name, double aspect, uint64_t seed, int64_t param,
+                         pt_scene **out, pt_camera *camera_out);
+void pt_scene_free(pt_scene *scene);
+int pt_scene_get_desc(const pt_scene *scene, pt_scene_desc *out);
+
+/* Generic builder: the operations of SceneBuilder (src/scene.rs:13-63) and MaterialBuilder
+ * (src/material.rs:80-131). Functions that create something return its index (>= 0) or a pt_status. */
+int pt_scene_new(uint64_t seed, pt_scene **out);
+int pt_scene_texture_constant(pt_scene *s, const double rgb[3]);
+int pt_scene_texture_checker(pt_scene *s, int even, int odd);
+int pt_scene_texture_noise(pt_scene *s, double scale);
+int pt_scene_texture_image(pt_scene *s, const uint8_t *rgb8, int width, int height);
+int pt_scene_material_lambertian(pt_scene *s, int texture, double emissive);
+int pt_scene_material_diffuse_light(pt_scene *s, int texture);
+int pt_scene_material_metal(pt_scene *s, const double albedo[3], double fuzz);
+int pt_scene_material_dielectric(pt_scene *s, double ref_idx);
+int pt_scene_sphere(pt_scene *s, const double center[3], double radius, int material);
+int pt_scene_moving_sphere(pt_scene *s, const double c0[3], const double c1[3], double t0, double t1,
+                           double radius, int material);
+int pt_scene_rect(pt_scene *s, double amin, double amax, double bmin, double bmax, double c, int axis,
+                  int material);
+int pt_scene_box(pt_scene *s, const double pmin[3], const double pmax[3], int material);
+int pt_scene_flip_normals(pt_scene *s, int node);
+int pt_scene_translate(pt_scene *s, int node, const double t[3]);
+int pt_scene_rotate_y(pt_scene *s, int node, double degrees);
+int pt_scene_constant_medium(pt_scene *s, int boundary, double density, int texture);
+int pt_scene_list(pt_scene *s, const int32_t *nodes, int n);
+/* BvhNode::from_list (src/bvh.rs:13-69) over the given nodes; axis draws come from the scene's seeded stream. */
+int pt_scene_bvh(pt_scene *s, const int32_t *nodes, int n, double time0, double time1);
+int pt_scene_set_root(pt_scene *s, int node);
+int pt_scene_set_lights(pt_scene *s, const int32_t *nodes, int n);
+/* bounding_box(t0, t1) of a node (src/hitable.rs:29); returns PT_ERR_INVALID_ARG for a LIST (unreachable!, 63-65). */
+int pt_scene_bounding_box(const pt_scene *s, int node, double t0, double t1, double min_out[3],
+                          double max_out[3]);
+
+/* Flattened device layout, for inspection by tests (no GPU needed). Returns counts through the out params. */
+int pt_scene_flatten_info(const pt_scene_desc *scene, int32_t *n_ops, int32_t *n_leaves, int32_t *n_xforms,
+                          int32_t *max_frame_depth);
+
+/* Reinhard(1.5) + sqrt gamma + u8 conversion with the row flip of the PPM writers
+ * (src/trace.rs:236-242, src/lib.rs:330-340,613-640). rgb8_out is width*height*3, top row first. */
+int pt_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8_out);
+
+uint32_t pt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

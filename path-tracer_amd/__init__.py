@@ -1,0 +1,484 @@
+"""ctypes binding of libptgpu.so, the MI355X render path for PathTracerRust.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("path-tracer_amd")`` (tests/conftest.py does this and
+exposes it as ``ptgpu``).  The binding is a thin mirror of include/ptgpu.h: the
+library is the product, this file only moves pointers.  There is no CPU
+fallback: if the shared library is missing the import raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()). "
+        "The HIP library is the only implementation of the render path; there is no fallback."
+    )
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+PT_OK = 0
+PT_ERR_INVALID_ARG = -1
+PT_ERR_UNSUPPORTED_SCENE = -2
+PT_ERR_NO_DEVICE = -3
+PT_ERR_HIP = -4
+PT_ERR_NO_SCENE = -5
+PT_ERR_NO_CAMERA = -6
+PT_ERR_OUT_OF_MEMORY = -7
+PT_ERR_TOO_LARGE = -8
+
+PT_MODE_OFFLINE = 0
+PT_MODE_REALTIME = 1
+PT_CFG_PROFILE_STAGES = 1
+PT_CFG_COUNT_TRAVERSAL = 2
+
+# pt_hitable_kind
+H_SPHERE, H_MOVING_SPHERE, H_RECT, H_BOX, H_LIST, H_FLIP, H_TRANSLATE, H_ROTATE_Y, H_MEDIUM, H_BVH = range(1, 11)
+AXIS_X, AXIS_Y, AXIS_Z = 0, 1, 2
+
+
+class Hitable(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("material", C.c_int32),
+        ("child", C.c_int32 * 2),
+        ("list_start", C.c_int32),
+        ("list_count", C.c_int32),
+        ("axis", C.c_int32),
+        ("reserved", C.c_int32),
+        ("f", C.c_double * 10),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("texture", C.c_int32),
+        ("albedo", C.c_double * 3),
+        ("fuzz", C.c_double),
+        ("ref_idx", C.c_double),
+        ("emissive", C.c_double),
+    ]
+
+
+class Texture(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("even", C.c_int32),
+        ("odd", C.c_int32),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("reserved", C.c_int32),
+        ("texel_offset", C.c_uint64),
+        ("colour", C.c_double * 3),
+        ("scale", C.c_double),
+    ]
+
+
+class Perlin(C.Structure):
+    _fields_ = [
+        ("ranvec", (C.c_double * 3) * 256),
+        ("perm_x", C.c_int32 * 256),
+        ("perm_y", C.c_int32 * 256),
+        ("perm_z", C.c_int32 * 256),
+    ]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("root", C.c_int32),
+        ("hitables", C.POINTER(Hitable)),
+        ("n_hitables", C.c_int32),
+        ("n_child_index", C.c_int32),
+        ("child_index", C.POINTER(C.c_int32)),
+        ("materials", C.POINTER(Material)),
+        ("textures", C.POINTER(Texture)),
+        ("n_materials", C.c_int32),
+        ("n_textures", C.c_int32),
+        ("texels", C.POINTER(C.c_uint8)),
+        ("n_texel_bytes", C.c_uint64),
+        ("perlin", C.POINTER(Perlin)),
+        ("lights", C.POINTER(C.c_int32)),
+        ("n_lights", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("origin", C.c_double * 3),
+        ("look_at", C.c_double * 3),
+        ("vup", C.c_double * 3),
+        ("vfov", C.c_double),
+        ("aspect", C.c_double),
+        ("aperture", C.c_double),
+        ("focus_dist", C.c_double),
+        ("time0", C.c_double),
+        ("time1", C.c_double),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("seed", C.c_uint64),
+        ("max_paths_in_flight", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("x0", C.c_uint32),
+        ("y0", C.c_uint32),
+        ("x1", C.c_uint32),
+        ("y1", C.c_uint32),
+        ("spp", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("mode", C.c_uint32),
+        ("frame", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("paths", C.c_uint64),
+        ("segments", C.c_uint64),
+        ("node_visits", C.c_uint64),
+        ("prim_tests", C.c_uint64),
+        ("nan_pixels", C.c_uint64),
+        ("launches_raygen", C.c_uint64),
+        ("launches_extend", C.c_uint64),
+        ("launches_shade", C.c_uint64),
+        ("launches_resolve", C.c_uint64),
+        ("ms_raygen", C.c_double),
+        ("ms_extend", C.c_double),
+        ("ms_shade", C.c_double),
+        ("ms_resolve", C.c_double),
+        ("profiled_segments", C.c_uint64),
+        ("profiled_paths", C.c_uint64),
+        ("profiled_passes", C.c_uint64),
+        ("profiled_bounce_launches", C.c_uint64),
+    ]
+
+
+# numpy views of pt_ray / pt_hit
+RAY_DTYPE = np.dtype([("origin", "<f8", (3,)), ("direction", "<f8", (3,)), ("time", "<f8")], align=True)
+HIT_DTYPE = np.dtype(
+    [("t", "<f8"), ("u", "<f8"), ("v", "<f8"), ("p", "<f8", (3,)), ("normal", "<f8", (3,)), ("prim", "<i4"), ("material", "<i4")],
+    align=True,
+)
+assert RAY_DTYPE.itemsize == 56 and HIT_DTYPE.itemsize == 80
+
+# Every symbol include/ptgpu.h declares.
+EXPORTS = [
+    "pt_create", "pt_destroy", "pt_last_error", "pt_scene_upload", "pt_camera_set", "pt_render", "pt_accum_reset",
+    "pt_readback", "pt_image_device_ptr", "pt_image_bind", "pt_intersect", "pt_stats_get", "pt_stats_reset",
+    "pt_stream", "pt_intersect_device", "pt_scene_build_named", "pt_scene_free", "pt_scene_get_desc", "pt_scene_new",
+    "pt_scene_texture_constant", "pt_scene_texture_checker", "pt_scene_texture_noise", "pt_scene_texture_image",
+    "pt_scene_material_lambertian", "pt_scene_material_diffuse_light", "pt_scene_material_metal",
+    "pt_scene_material_dielectric", "pt_scene_sphere", "pt_scene_moving_sphere", "pt_scene_rect", "pt_scene_box",
+    "pt_scene_flip_normals", "pt_scene_translate", "pt_scene_rotate_y", "pt_scene_constant_medium", "pt_scene_list",
+    "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
+    "pt_tonemap_rgb8", "pt_abi_version",
+]
+
+_vp = C.c_void_p
+_d3 = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("pt_create", C.c_int, C.POINTER(Config), C.POINTER(_vp))
+_sig("pt_destroy", None, _vp)
+_sig("pt_last_error", C.c_char_p, _vp)
+_sig("pt_scene_upload", C.c_int, _vp, C.POINTER(SceneDesc))
+_sig("pt_camera_set", C.c_int, _vp, C.POINTER(Camera))
+_sig("pt_render", C.c_int, _vp, C.POINTER(RenderArgs))
+_sig("pt_accum_reset", C.c_int, _vp)
+_sig("pt_readback", C.c_int, _vp, C.POINTER(C.c_float), C.c_size_t)
+_sig("pt_image_device_ptr", _vp, _vp)
+_sig("pt_image_bind", C.c_int, _vp, _vp, C.c_uint32, C.c_uint32)
+_sig("pt_intersect", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
+_sig("pt_stats_get", C.c_int, _vp, C.POINTER(Stats))
+_sig("pt_stats_reset", C.c_int, _vp)
+_sig("pt_stream", _vp, _vp)
+_sig("pt_intersect_device", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_int, _d3)
+_sig("pt_scene_build_named", C.c_int, C.c_char_p, C.c_double, C.c_uint64, C.c_int64, C.POINTER(_vp), C.POINTER(Camera))
+_sig("pt_scene_free", None, _vp)
+_sig("pt_scene_get_desc", C.c_int, _vp, C.POINTER(SceneDesc))
+_sig("pt_scene_new", C.c_int, C.c_uint64, C.POINTER(_vp))
+_sig("pt_scene_texture_constant", C.c_int, _vp, _d3)
+_sig("pt_scene_texture_checker", C.c_int, _vp, C.c_int, C.c_int)
+_sig("pt_scene_texture_noise", C.c_int, _vp, C.c_double)
+_sig("pt_scene_texture_image", C.c_int, _vp, C.POINTER(C.c_uint8), C.c_int, C.c_int)
+_sig("pt_scene_material_lambertian", C.c_int, _vp, C.c_int, C.c_double)
+_sig("pt_scene_material_diffuse_light", C.c_int, _vp, C.c_int)
+_sig("pt_scene_material_metal", C.c_int, _vp, _d3, C.c_double)
+_sig("pt_scene_material_dielectric", C.c_int, _vp, C.c_double)
+_sig("pt_scene_sphere", C.c_int, _vp, _d3, C.c_double, C.c_int)
+_sig("pt_scene_moving_sphere", C.c_int, _vp, _d3, _d3, C.c_double, C.c_double, C.c_double, C.c_int)
+_sig("pt_scene_rect", C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int)
+_sig("pt_scene_box", C.c_int, _vp, _d3, _d3, C.c_int)
+_sig("pt_scene_flip_normals", C.c_int, _vp, C.c_int)
+_sig("pt_scene_translate", C.c_int, _vp, C.c_int, _d3)
+_sig("pt_scene_rotate_y", C.c_int, _vp, C.c_int, C.c_double)
+_sig("pt_scene_constant_medium", C.c_int, _vp, C.c_int, C.c_double, C.c_int)
+_sig("pt_scene_list", C.c_int, _vp, _i32p, C.c_int)
+_sig("pt_scene_bvh", C.c_int, _vp, _i32p, C.c_int, C.c_double, C.c_double)
+_sig("pt_scene_set_root", C.c_int, _vp, C.c_int)
+_sig("pt_scene_set_lights", C.c_int, _vp, _i32p, C.c_int)
+_sig("pt_scene_bounding_box", C.c_int, _vp, C.c_int, C.c_double, C.c_double, _d3, _d3)
+_sig("pt_scene_flatten_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p, _i32p)
+_sig("pt_tonemap_rgb8", C.c_int, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8))
+_sig("pt_abi_version", C.c_uint32)
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"ptgpu error {code}: {msg}")
+        self.code = code
+
+
+def _vec(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def _ints(v):
+    return (C.c_int32 * len(v))(*[int(x) for x in v])
+
+
+def _check_id(rc, what):
+    if rc < 0:
+        raise PtError(rc, what)
+    return rc
+
+
+class Scene:
+    """Host-side scene: a named recipe of the reference or one built node by node (SceneBuilder mirror)."""
+
+    def __init__(self, seed=0x5EED0001):
+        self._h = _vp()
+        self.camera = None
+        rc = lib.pt_scene_new(C.c_uint64(seed), C.byref(self._h))
+        if rc != PT_OK:
+            raise PtError(rc, "pt_scene_new")
+
+    @classmethod
+    def named(cls, name, aspect=1.0, seed=0x5EED0001, param=0):
+        self = cls.__new__(cls)
+        self._h = _vp()
+        cam = Camera()
+        rc = lib.pt_scene_build_named(name.encode(), float(aspect), C.c_uint64(seed), C.c_int64(param), C.byref(self._h), C.byref(cam))
+        if rc != PT_OK:
+            raise PtError(rc, f"pt_scene_build_named({name})")
+        self.camera = cam
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.pt_scene_free(h)
+            self._h = None
+
+    def desc(self) -> SceneDesc:
+        d = SceneDesc()
+        rc = lib.pt_scene_get_desc(self._h, C.byref(d))
+        if rc != PT_OK:
+            raise PtError(rc, "pt_scene_get_desc")
+        return d
+
+    # textures / materials
+    def texture_constant(self, rgb): return _check_id(lib.pt_scene_texture_constant(self._h, _vec(rgb)), "texture_constant")
+    def texture_checker(self, even, odd): return _check_id(lib.pt_scene_texture_checker(self._h, even, odd), "texture_checker")
+    def texture_noise(self, scale): return _check_id(lib.pt_scene_texture_noise(self._h, float(scale)), "texture_noise")
+
+    def texture_image(self, rgb8):
+        a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w, c = a.shape
+        assert c == 3
+        return _check_id(lib.pt_scene_texture_image(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h), "texture_image")
+
+    def lambertian(self, texture, emissive=0.0): return _check_id(lib.pt_scene_material_lambertian(self._h, texture, float(emissive)), "lambertian")
+    def diffuse_light(self, texture): return _check_id(lib.pt_scene_material_diffuse_light(self._h, texture), "diffuse_light")
+    def metal(self, albedo, fuzz): return _check_id(lib.pt_scene_material_metal(self._h, _vec(albedo), float(fuzz)), "metal")
+    def dielectric(self, ref_idx): return _check_id(lib.pt_scene_material_dielectric(self._h, float(ref_idx)), "dielectric")
+
+    # hitables
+    def sphere(self, center, radius, material): return _check_id(lib.pt_scene_sphere(self._h, _vec(center), float(radius), material), "sphere")
+
+    def moving_sphere(self, c0, c1, t0, t1, radius, material):
+        return _check_id(lib.pt_scene_moving_sphere(self._h, _vec(c0), _vec(c1), float(t0), float(t1), float(radius), material), "moving_sphere")
+
+    def rect(self, amin, amax, bmin, bmax, c, axis, material):
+        return _check_id(lib.pt_scene_rect(self._h, float(amin), float(amax), float(bmin), float(bmax), float(c), axis, material), "rect")
+
+    def box(self, pmin, pmax, material): return _check_id(lib.pt_scene_box(self._h, _vec(pmin), _vec(pmax), material), "box")
+    def flip_normals(self, node): return _check_id(lib.pt_scene_flip_normals(self._h, node), "flip_normals")
+    def translate(self, node, t): return _check_id(lib.pt_scene_translate(self._h, node, _vec(t)), "translate")
+    def rotate_y(self, node, degrees): return _check_id(lib.pt_scene_rotate_y(self._h, node, float(degrees)), "rotate_y")
+
+    def constant_medium(self, boundary, density, texture):
+        return _check_id(lib.pt_scene_constant_medium(self._h, boundary, float(density), texture), "constant_medium")
+
+    def list(self, nodes): return _check_id(lib.pt_scene_list(self._h, _ints(nodes), len(nodes)), "list")
+
+    def bvh(self, nodes, time0=0.0, time1=1.0):
+        return _check_id(lib.pt_scene_bvh(self._h, _ints(nodes), len(nodes), float(time0), float(time1)), "bvh")
+
+    def set_root(self, node):
+        rc = lib.pt_scene_set_root(self._h, node)
+        if rc != PT_OK:
+            raise PtError(rc, "set_root")
+
+    def set_lights(self, nodes):
+        rc = lib.pt_scene_set_lights(self._h, _ints(nodes), len(nodes))
+        if rc != PT_OK:
+            raise PtError(rc, "set_lights")
+
+    def bounding_box(self, node, t0=0.0, t1=1.0):
+        mn, mx = (C.c_double * 3)(), (C.c_double * 3)()
+        rc = lib.pt_scene_bounding_box(self._h, node, float(t0), float(t1), mn, mx)
+        if rc != PT_OK:
+            raise PtError(rc, "bounding_box")
+        return np.array(mn), np.array(mx)
+
+    def flatten_info(self):
+        d = self.desc()
+        v = [C.c_int32() for _ in range(4)]
+        rc = lib.pt_scene_flatten_info(C.byref(d), *[C.byref(x) for x in v])
+        if rc != PT_OK:
+            raise PtError(rc, "flatten_info")
+        return dict(zip(("n_ops", "n_leaves", "n_xforms", "max_frame_depth"), [x.value for x in v]))
+
+
+def make_camera(origin, look_at, vup=(0, 1, 0), vfov=40.0, aspect=1.0, aperture=0.0, focus_dist=10.0, time0=0.0, time1=1.0):
+    c = Camera()
+    c.origin[:] = [float(x) for x in origin]
+    c.look_at[:] = [float(x) for x in look_at]
+    c.vup[:] = [float(x) for x in vup]
+    c.vfov, c.aspect, c.aperture, c.focus_dist, c.time0, c.time1 = map(float, (vfov, aspect, aperture, focus_dist, time0, time1))
+    return c
+
+
+class Context:
+    """One GPU's render state (pt_ctx)."""
+
+    def __init__(self, device=0, seed=0x5EED0001, max_paths_in_flight=0, flags=0):
+        cfg = Config(C.sizeof(Config), device, seed, max_paths_in_flight, flags)
+        self._h = _vp()
+        rc = lib.pt_create(C.byref(cfg), C.byref(self._h))
+        if rc != PT_OK:
+            raise PtError(rc, "pt_create (no usable HIP device?)" if rc == PT_ERR_NO_DEVICE else "pt_create")
+        self.seed = seed
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != PT_OK:
+            raise PtError(rc, f"{what}: {lib.pt_last_error(self._h).decode(errors='replace')}")
+
+    def upload(self, scene: Scene):
+        d = scene.desc()
+        self._check(lib.pt_scene_upload(self._h, C.byref(d)), "pt_scene_upload")
+        if scene.camera is not None:
+            self.set_camera(scene.camera)
+
+    def upload_desc(self, desc: SceneDesc):
+        self._check(lib.pt_scene_upload(self._h, C.byref(desc)), "pt_scene_upload")
+
+    def set_camera(self, cam: Camera):
+        self._check(lib.pt_camera_set(self._h, C.byref(cam)), "pt_camera_set")
+
+    def render(self, width, height, spp, max_depth, tile=None, mode=PT_MODE_OFFLINE, frame=0):
+        x0, y0, x1, y1 = tile if tile is not None else (0, 0, width, height)
+        a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, 0)
+        self._check(lib.pt_render(self._h, C.byref(a)), "pt_render")
+        self.width, self.height = width, height
+
+    def reset(self):
+        self._check(lib.pt_accum_reset(self._h), "pt_accum_reset")
+
+    def readback(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(lib.pt_readback(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pt_readback")
+        return out
+
+    def bind_image(self, device_ptr, width, height):
+        self._check(lib.pt_image_bind(self._h, _vp(device_ptr), width, height), "pt_image_bind")
+        self.width, self.height = width, height
+
+    def image_device_ptr(self):
+        return lib.pt_image_device_ptr(self._h)
+
+    def stream(self):
+        return lib.pt_stream(self._h)
+
+    def intersect(self, rays, t_min=0.001, t_max=np.finfo(np.float64).max, medium_seed=0):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        self._check(
+            lib.pt_intersect(self._h, rays.ctypes.data, rays.shape[0], float(t_min), float(t_max), C.c_uint64(medium_seed), hits.ctypes.data),
+            "pt_intersect",
+        )
+        return hits
+
+    def intersect_device(self, d_rays_soa_ptr, n, t_min=0.001, t_max=np.finfo(np.float64).max, medium_seed=0, repeats=1):
+        ms = C.c_double()
+        self._check(
+            lib.pt_intersect_device(self._h, _vp(d_rays_soa_ptr), n, float(t_min), float(t_max), C.c_uint64(medium_seed), repeats, C.byref(ms)),
+            "pt_intersect_device",
+        )
+        return ms.value
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._check(lib.pt_stats_get(self._h, C.byref(s)), "pt_stats_get")
+        return s
+
+    def stats_reset(self):
+        self._check(lib.pt_stats_reset(self._h), "pt_stats_reset")
+
+
+def tonemap_rgb8(rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w, _ = rgba.shape
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    rc = lib.pt_tonemap_rgb8(rgba.ctypes.data_as(C.POINTER(C.c_float)), w, h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc != PT_OK:
+        raise PtError(rc, "pt_tonemap_rgb8")
+    return out
+
+
+def write_ppm(path, rgb8):
+    """P6 writer with the header of src/lib.rs:603."""
+    h, w, _ = rgb8.shape
+    with open(path, "wb") as f:
+        f.write(f"P6 {w} {h} 255\n".encode())
+        f.write(np.ascontiguousarray(rgb8, dtype=np.uint8).tobytes())

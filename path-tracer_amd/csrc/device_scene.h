@@ -1,0 +1,73 @@
+// Device layout of a flattened scene. Shared by the host flattener and the HIP kernels.
+//
+// The reference walks a tree of Arc<dyn Hitable> recursively, always left child first
+// (src/bvh.rs:74-99). Because that order is fixed, the tree is stored here as a *threaded* pre-order
+// op stream: every BVH node becomes a BOX op that either falls through to the next op (its left
+// subtree) or jumps to `skip` (the first op after its subtree). Traversal therefore needs no stack,
+// visits primitives in exactly the reference's order, and keeps the reference's "shrinking t_max".
+//
+// Wrapper nodes (FlipNormals / Translate / RotateY, src/hitable.rs:80-216) are not ops: they are folded
+// into per-leaf transform chains that are applied op by op, in the wrappers' nesting order, so the
+// arithmetic matches the reference's nested calls. A wrapped BVH subtree becomes ENTER ... EXIT.
+#pragma once
+
+#include <stdint.h>
+
+namespace ptdev {
+
+enum OpKind : int32_t {
+    OP_BOX = 0,     // d = min xyz, max xyz ; skip = op to jump to on a miss
+    OP_SPHERE = 1,  // d = center xyz, radius
+    OP_RECT = 2,    // d = amin amax bmin bmax c ; axis
+    OP_BOXPRIM = 3, // d = pmin xyz, pmax xyz (the six faces of AxisAlignedBox, src/axis_aligned_box.rs:17-22)
+    OP_MSPHERE = 4, // d = center0 xyz, radius, time0, time_range ; leaf.e = center_range xyz
+    OP_MEDIUM = 5,  // d[0] = density ; skip = index of the boundary op (stored after the traversal ops)
+    OP_ENTER = 6,   // enter a transformed subtree: apply chain [chain_start, +chain_count) to the current ray
+    OP_EXIT = 7     // leave it: current ray = world ray transformed by chain [chain_start, +chain_count)
+};
+
+struct DevOp { // 64 bytes
+    double d[6];
+    int32_t kind;        // OpKind | axis << 8
+    int32_t skip;
+    int32_t leaf;        // leaf id for primitive ops, -1 otherwise
+    int32_t chain_start; // first transform of the chain this op applies (local to the current frame)
+    // chain_count lives in the top byte of `kind` to keep the record at 64 bytes
+};
+static_assert(sizeof(DevOp) == 64, "DevOp must be 64 bytes");
+
+inline int op_kind(int32_t k) { return k & 0xff; }
+inline int op_axis(int32_t k) { return (k >> 8) & 0x3; }
+inline int op_chain_count(int32_t k) { return (k >> 16) & 0xff; }
+inline int32_t op_pack(int kind, int axis, int chain_count) { return kind | (axis << 8) | (chain_count << 16); }
+
+enum XformKind : int32_t { XF_TRANSLATE = 0, XF_ROTATE_Y = 1, XF_FLIP = 2 };
+struct DevXform { // 32 bytes
+    int32_t kind;
+    int32_t pad;
+    double a, b, c; // TRANSLATE: xyz ; ROTATE_Y: a = sin, b = cos
+};
+static_assert(sizeof(DevXform) == 32, "DevXform must be 32 bytes");
+
+struct DevLeaf { // 96 bytes: what finalising a hit needs beyond the op itself
+    int32_t op;          // op holding the geometry parameters
+    int32_t material;
+    int32_t full_start;  // full chain world -> leaf space
+    int32_t full_count;
+    int32_t prim[6];     // graph node reported as pt_hit.prim ([0] unless BOXPRIM, where it is per face)
+    int32_t kind;        // OpKind of the geometry
+    int32_t axis;
+    double e[3];         // MSPHERE: center_range
+    double pad[3];
+};
+static_assert(sizeof(DevLeaf) == 96, "DevLeaf must be 96 bytes");
+
+enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_SPHERE = 1, LIGHT_RECT = 2 };
+struct DevLight { // 48 bytes: a shape of the light list (src/trace.rs:123-128)
+    int32_t kind;
+    int32_t axis;
+    double d[5]; // SPHERE: center xyz, radius ; RECT: amin amax bmin bmax c
+};
+static_assert(sizeof(DevLight) == 48, "DevLight must be 48 bytes");
+
+} // namespace ptdev

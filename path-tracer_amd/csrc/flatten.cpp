@@ -1,0 +1,362 @@
+// Scene graph -> threaded op stream. See device_scene.h for the layout and its rationale.
+#include "flatten.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace ptdev {
+
+namespace {
+
+struct FrameRef {
+    int32_t start = 0; // range of the frame's full chain in xforms[]
+    int32_t count = 0;
+};
+
+class Flattener {
+  public:
+    Flattener(const pt_scene_desc *s, FlatScene &out, std::string &err) : s_(s), out_(out), err_(err) {}
+
+    int run() {
+        if (!s_ || s_->struct_size != sizeof(pt_scene_desc)) return fail(PT_ERR_INVALID_ARG, "bad pt_scene_desc size");
+        if (s_->n_hitables <= 0 || !s_->hitables) return fail(PT_ERR_INVALID_ARG, "scene has no hitables");
+        if (!node_ok(s_->root)) return fail(PT_ERR_INVALID_ARG, "scene root out of range");
+        if (s_->n_materials < 0 || s_->n_textures < 0 || s_->n_lights < 0)
+            return fail(PT_ERR_INVALID_ARG, "negative table size");
+        for (int i = 0; i < s_->n_materials; ++i) {
+            const pt_material &m = s_->materials[i];
+            bool needs_tex = m.kind == PT_M_LAMBERTIAN || m.kind == PT_M_DIFFUSE_LIGHT || m.kind == PT_M_ISOTROPIC;
+            if (m.kind < PT_M_DUMMY || m.kind > PT_M_ISOTROPIC) return fail(PT_ERR_INVALID_ARG, "bad material kind");
+            if (needs_tex && (m.texture < 0 || m.texture >= s_->n_textures))
+                return fail(PT_ERR_INVALID_ARG, "material texture out of range");
+        }
+        for (int i = 0; i < s_->n_textures; ++i) {
+            const pt_texture &t = s_->textures[i];
+            if (t.kind < PT_T_CONSTANT || t.kind > PT_T_IMAGE) return fail(PT_ERR_INVALID_ARG, "bad texture kind");
+            if (t.kind == PT_T_CHECKER &&
+                (t.even < 0 || t.even >= s_->n_textures || t.odd < 0 || t.odd >= s_->n_textures))
+                return fail(PT_ERR_INVALID_ARG, "checker child texture out of range");
+            if (t.kind == PT_T_CHECKER && (t.even >= i || t.odd >= i))
+                return fail(PT_ERR_UNSUPPORTED_SCENE, "checker children must be created before the checker");
+            if (t.kind == PT_T_NOISE && !s_->perlin) return fail(PT_ERR_INVALID_ARG, "noise texture without perlin tables");
+            if (t.kind == PT_T_IMAGE) {
+                if (t.width <= 0 || t.height <= 0 || !s_->texels ||
+                    t.texel_offset + (uint64_t)t.width * t.height * 3 > s_->n_texel_bytes)
+                    return fail(PT_ERR_INVALID_ARG, "image texture outside the texel blob");
+            }
+        }
+        std::vector<DevXform> local, full;
+        int rc = emit(s_->root, local, full, FrameRef{}, 0, true, 0);
+        if (rc != PT_OK) return rc;
+        out_.n_traversal_ops = (int32_t)out_.ops.size();
+        // boundary ops of media are stored behind the traversal stream
+        for (auto &op : out_.ops)
+            if (op_kind(op.kind) == OP_MEDIUM) op.skip += out_.n_traversal_ops;
+        out_.ops.insert(out_.ops.end(), boundary_ops_.begin(), boundary_ops_.end());
+        if (out_.ops.empty()) return fail(PT_ERR_INVALID_ARG, "scene flattened to nothing");
+
+        for (int i = 0; i < s_->n_lights; ++i) {
+            int h = s_->lights[i];
+            if (!node_ok(h)) return fail(PT_ERR_INVALID_ARG, "light node out of range");
+            const pt_hitable &n = s_->hitables[h];
+            DevLight l;
+            std::memset(&l, 0, sizeof(l));
+            if (n.kind == PT_H_SPHERE) {
+                l.kind = LIGHT_SPHERE;
+                for (int k = 0; k < 4; ++k) l.d[k] = n.f[k];
+            } else if (n.kind == PT_H_RECT) {
+                l.kind = LIGHT_RECT;
+                l.axis = n.axis;
+                for (int k = 0; k < 5; ++k) l.d[k] = n.f[k];
+            } else if (n.kind == PT_H_LIST) {
+                return fail(PT_ERR_UNSUPPORTED_SCENE, "nested HitableList in the light list");
+            } else {
+                l.kind = LIGHT_OTHER; // trait defaults: pdf_value 0, random (1,0,0) (src/hitable.rs:30-35)
+            }
+            out_.lights.push_back(l);
+        }
+        return PT_OK;
+    }
+
+  private:
+    bool node_ok(int h) const { return h >= 0 && h < s_->n_hitables; }
+    int fail(int code, const std::string &msg) {
+        if (err_.empty()) err_ = msg;
+        return code;
+    }
+
+    // Appends `full` ++ `local` to xforms[] and returns where it starts (0 if the chain is empty).
+    int32_t store_chain(const std::vector<DevXform> &full, const std::vector<DevXform> &local) {
+        if (full.empty() && local.empty()) return 0;
+        int32_t start = (int32_t)out_.xforms.size();
+        out_.xforms.insert(out_.xforms.end(), full.begin(), full.end());
+        out_.xforms.insert(out_.xforms.end(), local.begin(), local.end());
+        return start;
+    }
+
+    static DevXform xf(int kind, double a, double b, double c) {
+        DevXform x;
+        x.kind = kind;
+        x.pad = 0;
+        x.a = a;
+        x.b = b;
+        x.c = c;
+        return x;
+    }
+
+    // Fills geometry parameters of a primitive op from a graph node. Returns false if not a primitive.
+    bool geometry_op(int h, DevOp &op, DevLeaf &leaf, int &rc) {
+        const pt_hitable &n = s_->hitables[h];
+        std::memset(&op, 0, sizeof(op));
+        std::memset(&leaf, 0, sizeof(leaf));
+        op.skip = -1;
+        for (int k = 0; k < 6; ++k) leaf.prim[k] = h;
+        leaf.material = n.material;
+        rc = PT_OK;
+        if ((n.kind == PT_H_SPHERE || n.kind == PT_H_MOVING_SPHERE || n.kind == PT_H_RECT || n.kind == PT_H_BOX) &&
+            (n.material < 0 || n.material >= s_->n_materials)) {
+            rc = fail(PT_ERR_INVALID_ARG, "primitive material out of range");
+            return true;
+        }
+        switch (n.kind) {
+        case PT_H_SPHERE:
+            leaf.kind = OP_SPHERE;
+            for (int k = 0; k < 4; ++k) op.d[k] = n.f[k];
+            return true;
+        case PT_H_MOVING_SPHERE:
+            leaf.kind = OP_MSPHERE;
+            op.d[0] = n.f[0]; op.d[1] = n.f[1]; op.d[2] = n.f[2]; op.d[3] = n.f[3];
+            op.d[4] = n.f[7]; op.d[5] = n.f[8];
+            leaf.e[0] = n.f[4]; leaf.e[1] = n.f[5]; leaf.e[2] = n.f[6];
+            return true;
+        case PT_H_RECT:
+            if (n.axis < 0 || n.axis > 2) {
+                rc = fail(PT_ERR_INVALID_ARG, "rect axis out of range");
+                return true;
+            }
+            leaf.kind = OP_RECT;
+            leaf.axis = n.axis;
+            for (int k = 0; k < 5; ++k) op.d[k] = n.f[k];
+            return true;
+        case PT_H_BOX: {
+            leaf.kind = OP_BOXPRIM;
+            for (int k = 0; k < 6; ++k) op.d[k] = n.f[k];
+            rc = check_box(h, leaf);
+            return true;
+        }
+        default:
+            return false;
+        }
+    }
+
+    // The device intersects a box as the six rectangles AxisAlignedBox::new builds (src/axis_aligned_box.rs:17-22);
+    // verify the graph's face list is exactly that, and record each face's node for pt_hit.prim.
+    int check_box(int h, DevLeaf &leaf) {
+        const pt_hitable &n = s_->hitables[h];
+        if (n.list_count != 6 || n.list_start < 0 || n.list_start + 6 > s_->n_child_index)
+            return fail(PT_ERR_UNSUPPORTED_SCENE, "box without its six faces");
+        const double *lo = &n.f[0], *hi = &n.f[3];
+        // face k: {a axis, b axis, plane axis, plane at hi?, flipped}
+        const int spec[6][5] = {{0, 1, 2, 1, 0}, {0, 1, 2, 0, 1}, {0, 2, 1, 1, 0},
+                                {0, 2, 1, 0, 1}, {1, 2, 0, 1, 0}, {1, 2, 0, 0, 1}};
+        for (int k = 0; k < 6; ++k) {
+            int c = s_->child_index[n.list_start + k];
+            if (!node_ok(c)) return fail(PT_ERR_INVALID_ARG, "box face out of range");
+            bool flipped = false;
+            if (s_->hitables[c].kind == PT_H_FLIP) {
+                flipped = true;
+                c = s_->hitables[c].child[0];
+                if (!node_ok(c)) return fail(PT_ERR_INVALID_ARG, "box face out of range");
+            }
+            const pt_hitable &r = s_->hitables[c];
+            const int *sp = spec[k];
+            bool ok = r.kind == PT_H_RECT && r.axis == sp[2] && flipped == (sp[4] == 1) && r.f[0] == lo[sp[0]] &&
+                      r.f[1] == hi[sp[0]] && r.f[2] == lo[sp[1]] && r.f[3] == hi[sp[1]] &&
+                      r.f[4] == (sp[3] ? hi[sp[2]] : lo[sp[2]]) && r.material == n.material;
+            if (!ok) return fail(PT_ERR_UNSUPPORTED_SCENE, "box faces differ from the canonical six rectangles");
+            leaf.prim[k] = c;
+        }
+        return PT_OK;
+    }
+
+    int emit(int h, std::vector<DevXform> local, const std::vector<DevXform> &full, FrameRef frame, int frame_depth,
+             bool is_root, int guard) {
+        if (!node_ok(h)) return fail(PT_ERR_INVALID_ARG, "hitable index out of range");
+        if (guard > 4096) return fail(PT_ERR_INVALID_ARG, "hitable graph too deep or cyclic");
+        const pt_hitable &n = s_->hitables[h];
+        switch (n.kind) {
+        case PT_H_FLIP:
+            local.push_back(xf(XF_FLIP, 0, 0, 0));
+            return emit(n.child[0], local, full, frame, frame_depth, false, guard + 1);
+        case PT_H_TRANSLATE:
+            local.push_back(xf(XF_TRANSLATE, n.f[0], n.f[1], n.f[2]));
+            return emit(n.child[0], local, full, frame, frame_depth, false, guard + 1);
+        case PT_H_ROTATE_Y:
+            local.push_back(xf(XF_ROTATE_Y, n.f[0], n.f[1], 0.0));
+            return emit(n.child[0], local, full, frame, frame_depth, false, guard + 1);
+        case PT_H_BVH: {
+            if (!local.empty()) {
+                // wrapped subtree: ENTER (apply the wrappers to the ray), the subtree, EXIT (restore)
+                if (local.size() > 255 || full.size() + local.size() > 255)
+                    return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+                int32_t start = store_chain(full, local);
+                std::vector<DevXform> new_full(full);
+                new_full.insert(new_full.end(), local.begin(), local.end());
+                DevOp enter;
+                std::memset(&enter, 0, sizeof(enter));
+                enter.kind = op_pack(OP_ENTER, 0, (int)local.size());
+                enter.skip = -1;
+                enter.leaf = -1;
+                enter.chain_start = start + (int32_t)full.size();
+                out_.ops.push_back(enter);
+                out_.has_frames = true;
+                if (frame_depth + 1 > out_.max_frame_depth) out_.max_frame_depth = frame_depth + 1;
+                FrameRef inner{start, (int32_t)new_full.size()};
+                int rc = emit(h, std::vector<DevXform>(), new_full, inner, frame_depth + 1, false, guard + 1);
+                if (rc != PT_OK) return rc;
+                DevOp exit_op;
+                std::memset(&exit_op, 0, sizeof(exit_op));
+                exit_op.kind = op_pack(OP_EXIT, 0, frame.count);
+                exit_op.skip = -1;
+                exit_op.leaf = -1;
+                exit_op.chain_start = frame.start;
+                out_.ops.push_back(exit_op);
+                return PT_OK;
+            }
+            DevOp box;
+            std::memset(&box, 0, sizeof(box));
+            box.kind = op_pack(OP_BOX, 0, 0);
+            box.leaf = -1;
+            for (int k = 0; k < 6; ++k) box.d[k] = n.f[k];
+            size_t at = out_.ops.size();
+            out_.ops.push_back(box);
+            int rc = emit(n.child[0], std::vector<DevXform>(), full, frame, frame_depth, false, guard + 1);
+            if (rc != PT_OK) return rc;
+            if (n.child[1] != n.child[0]) { // bvh.rs:47-49 duplicates a lone leaf; testing it once is equivalent
+                rc = emit(n.child[1], std::vector<DevXform>(), full, frame, frame_depth, false, guard + 1);
+                if (rc != PT_OK) return rc;
+            }
+            if (out_.ops.size() > (size_t)INT32_MAX) return fail(PT_ERR_TOO_LARGE, "too many ops");
+            out_.ops[at].skip = (int32_t)out_.ops.size();
+            return PT_OK;
+        }
+        case PT_H_LIST: {
+            if (!is_root || !local.empty())
+                return fail(PT_ERR_UNSUPPORTED_SCENE, "HitableList is only supported as the scene root");
+            if (n.list_start < 0 || n.list_count < 0 || n.list_start + n.list_count > s_->n_child_index)
+                return fail(PT_ERR_INVALID_ARG, "list range out of bounds");
+            for (int k = 0; k < n.list_count; ++k) {
+                int rc = emit(s_->child_index[n.list_start + k], std::vector<DevXform>(), full, frame, frame_depth,
+                              false, guard + 1);
+                if (rc != PT_OK) return rc;
+            }
+            return PT_OK;
+        }
+        case PT_H_MEDIUM: {
+            if (n.material < 0 || n.material >= s_->n_materials)
+                return fail(PT_ERR_INVALID_ARG, "medium phase function out of range");
+            if (full.size() + local.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+            // boundary: wrappers down to one primitive
+            std::vector<DevXform> inner;
+            int b = n.child[0];
+            for (int g = 0;; ++g) {
+                if (!node_ok(b) || g > 255) return fail(PT_ERR_INVALID_ARG, "medium boundary out of range");
+                const pt_hitable &bn = s_->hitables[b];
+                if (bn.kind == PT_H_FLIP) inner.push_back(xf(XF_FLIP, 0, 0, 0));
+                else if (bn.kind == PT_H_TRANSLATE) inner.push_back(xf(XF_TRANSLATE, bn.f[0], bn.f[1], bn.f[2]));
+                else if (bn.kind == PT_H_ROTATE_Y) inner.push_back(xf(XF_ROTATE_Y, bn.f[0], bn.f[1], 0.0));
+                else break;
+                b = bn.child[0];
+            }
+            DevOp bop;
+            DevLeaf bleaf;
+            int rc = PT_OK;
+            if (!geometry_op(b, bop, bleaf, rc))
+                return fail(PT_ERR_UNSUPPORTED_SCENE, "medium boundary must be a (wrapped) sphere, rect or box");
+            if (rc != PT_OK) return rc;
+            int32_t istart = store_chain(std::vector<DevXform>(), inner);
+            bleaf.op = -1; // fixed below
+            bleaf.full_start = istart;
+            bleaf.full_count = (int32_t)inner.size();
+            bop.kind = op_pack(bleaf.kind, bleaf.axis, (int)inner.size());
+            bop.chain_start = istart;
+            bop.leaf = (int32_t)out_.leaves.size();
+            out_.leaves.push_back(bleaf);
+            int32_t bindex = (int32_t)boundary_ops_.size();
+            boundary_ops_.push_back(bop);
+
+            int32_t start = store_chain(full, local);
+            DevLeaf leaf;
+            std::memset(&leaf, 0, sizeof(leaf));
+            leaf.kind = OP_MEDIUM;
+            leaf.material = n.material;
+            leaf.full_start = start;
+            leaf.full_count = (int32_t)(full.size() + local.size());
+            for (int k = 0; k < 6; ++k) leaf.prim[k] = h;
+            leaf.op = (int32_t)out_.ops.size();
+            DevOp op;
+            std::memset(&op, 0, sizeof(op));
+            op.kind = op_pack(OP_MEDIUM, 0, (int)local.size());
+            op.d[0] = n.f[0];
+            op.skip = bindex; // relocated once the traversal stream is complete
+            op.leaf = (int32_t)out_.leaves.size();
+            op.chain_start = start + (int32_t)full.size();
+            out_.leaves.push_back(leaf);
+            out_.ops.push_back(op);
+            out_.has_medium = true;
+            return PT_OK;
+        }
+        default: {
+            DevOp op;
+            DevLeaf leaf;
+            int rc = PT_OK;
+            if (!geometry_op(h, op, leaf, rc)) return fail(PT_ERR_INVALID_ARG, "unknown hitable kind");
+            if (rc != PT_OK) return rc;
+            if (full.size() + local.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+            if (out_.leaves.size() >= (size_t)(1 << 28)) return fail(PT_ERR_TOO_LARGE, "too many primitives");
+            int32_t start = store_chain(full, local);
+            leaf.full_start = start;
+            leaf.full_count = (int32_t)(full.size() + local.size());
+            leaf.op = (int32_t)out_.ops.size();
+            op.kind = op_pack(leaf.kind, leaf.axis, (int)local.size());
+            op.chain_start = start + (int32_t)full.size();
+            op.leaf = (int32_t)out_.leaves.size();
+            out_.leaves.push_back(leaf);
+            out_.ops.push_back(op);
+            return PT_OK;
+        }
+        }
+    }
+
+    const pt_scene_desc *s_;
+    FlatScene &out_;
+    std::string &err_;
+    std::vector<DevOp> boundary_ops_;
+};
+
+} // namespace
+
+int flatten_scene(const pt_scene_desc *scene, FlatScene &out, std::string &error) {
+    out = FlatScene();
+    Flattener f(scene, out, error);
+    int rc = f.run();
+    if (rc != PT_OK) return rc;
+    // boundary leaves point at their op once the boundary ops have been appended
+    for (size_t i = (size_t)out.n_traversal_ops; i < out.ops.size(); ++i) out.leaves[out.ops[i].leaf].op = (int32_t)i;
+    return PT_OK;
+}
+
+} // namespace ptdev
+
+extern "C" int pt_scene_flatten_info(const pt_scene_desc *scene, int32_t *n_ops, int32_t *n_leaves, int32_t *n_xforms,
+                                     int32_t *max_frame_depth) {
+    ptdev::FlatScene flat;
+    std::string err;
+    int rc = ptdev::flatten_scene(scene, flat, err);
+    if (rc != PT_OK) return rc;
+    if (n_ops) *n_ops = flat.n_traversal_ops;
+    if (n_leaves) *n_leaves = (int32_t)flat.leaves.size();
+    if (n_xforms) *n_xforms = (int32_t)flat.xforms.size();
+    if (max_frame_depth) *max_frame_depth = flat.max_frame_depth;
+    return PT_OK;
+}

@@ -1,0 +1,575 @@
+// Device-side arithmetic of the render path: vectors, the counter RNG, primitive tests, hit finalisation,
+// textures, materials and light sampling. Everything is f64, the reference's arithmetic type, and is
+// compiled with -ffp-contract=off so that products and sums round exactly as in the reference (Rust never
+// fuses a*b+c). FP64 vector rate on gfx950 is half the FP32 rate, which is what makes this affordable.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptgpu.h"
+#include "device_scene.h"
+
+namespace ptdev {
+
+#define PT_DEV __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double kFracPi2 = 1.57079632679489661923132169163975144;
+constexpr double kFrac1Pi = 0.318309886183790671537767526745028724;
+constexpr double kF64Max = 1.7976931348623157e308;
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
+
+// ------------------------------------------------------------------- RNG --
+// SplitMix64 finaliser; a path's n-th draw is mix64(key + n * golden). Stands in for random::rand
+// (src/math/random.rs:3-6), which is an OS-seeded thread_rng and cannot be reproduced.
+PT_DEV uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+PT_DEV double to_unit(uint64_t x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+struct Rng {
+    uint64_t key;
+    uint32_t n;
+    PT_DEV double next() {
+        n += 1;
+        return to_unit(mix64(key + (uint64_t)n * kGolden));
+    }
+};
+PT_DEV uint64_t path_key(uint64_t seed, uint64_t frame, uint64_t pixel, uint64_t sample) {
+    uint64_t k = mix64(seed ^ (0xA0761D6478BD642FULL * (frame + 1)));
+    k = mix64(k ^ pixel);
+    k = mix64(k + kGolden * (sample + 1));
+    return k;
+}
+PT_DEV double medium_draw(uint64_t pkey, uint32_t depth, int32_t medium_node) {
+    uint64_t salt = mix64(0x4D454449554D0000ULL + ((uint64_t)depth << 32) + (uint64_t)(uint32_t)medium_node);
+    return to_unit(mix64(pkey ^ salt));
+}
+PT_DEV double pixel_skip_draw(uint64_t seed, uint64_t frame, uint64_t pixel) {
+    uint64_t k = mix64(seed ^ 0x534B495050495845ULL ^ (0xA0761D6478BD642FULL * (frame + 1)));
+    return to_unit(mix64(k ^ pixel));
+}
+PT_DEV uint64_t intersect_key(uint64_t medium_seed, uint64_t i) { return mix64(medium_seed ^ mix64(i + kGolden)); }
+
+// ------------------------------------------------------------------ Vec3 --
+struct D3 {
+    double x, y, z;
+};
+PT_DEV D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+PT_DEV D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PT_DEV D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PT_DEV D3 operator*(D3 a, D3 b) { return D3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+PT_DEV D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+PT_DEV D3 operator*(double s, D3 a) { return D3{a.x * s, a.y * s, a.z * s}; }
+PT_DEV D3 operator/(D3 a, double s) { return D3{a.x / s, a.y / s, a.z / s}; }
+PT_DEV D3 operator-(D3 a) { return D3{-a.x, -a.y, -a.z}; }
+PT_DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV D3 cross(D3 a, D3 b) { // src/math/vec3.rs:137-143
+    return D3{a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x};
+}
+PT_DEV double squared_length(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+PT_DEV double length(D3 a) { return sqrt(squared_length(a)); }
+PT_DEV D3 unit_vector(D3 a) { return a / length(a); }
+
+struct RayD {
+    D3 o, d;
+    double time;
+};
+
+// ---------------------------------------------------------- scene tables --
+struct SceneView {
+    const DevOp *ops;
+    const DevXform *xforms;
+    const DevLeaf *leaves;
+    const DevLight *lights;
+    const pt_material *materials;
+    const pt_texture *textures;
+    const uint8_t *texels;
+    const pt_perlin *perlin;
+    int32_t n_traversal_ops;
+    int32_t n_lights;
+    int32_t has_medium;
+    int32_t has_frames;
+};
+
+// ------------------------------------------------------------ transforms --
+// Ray into a wrapper's child space: Translate::hit (src/hitable.rs:124) and RotateY::hit (204-206, via 182-187).
+PT_DEV void xform_ray(const DevXform &x, D3 &o, D3 &d) {
+    if (x.kind == XF_TRANSLATE) {
+        o = o - d3(x.a, x.b, x.c);
+    } else if (x.kind == XF_ROTATE_Y) {
+        const double s = x.a, c = x.b;
+        o = d3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
+        d = d3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+    }
+}
+PT_DEV void apply_chain(const DevXform *xf, int start, int count, D3 &o, D3 &d) {
+    for (int k = 0; k < count; ++k) xform_ray(xf[start + k], o, d);
+}
+// Hit record back out of a wrapper: hitable.rs:95 (flip), 126 (translate), 209-210 (rotate, via 189-194).
+PT_DEV void unxform_hit(const DevXform &x, D3 &p, D3 &n) {
+    if (x.kind == XF_TRANSLATE) {
+        p = p + d3(x.a, x.b, x.c);
+    } else if (x.kind == XF_ROTATE_Y) {
+        const double s = x.a, c = x.b;
+        p = d3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+        n = d3(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
+    } else {
+        n = -n;
+    }
+}
+
+// ------------------------------------------------------------ primitives --
+// AABB::hit (src/math/aabb.rs:27-47). inv = 1/d per axis is hoisted out of the per-node loop: the reference
+// recomputes the same quotient at every node, so the values are identical.
+PT_DEV bool aabb_hit(const double *b, D3 o, D3 inv, double tmin, double tmax) {
+    {
+        double t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
+        if (inv.x < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    {
+        double t0 = (b[1] - o.y) * inv.y, t1 = (b[4] - o.y) * inv.y;
+        if (inv.y < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    {
+        double t0 = (b[2] - o.z) * inv.z, t1 = (b[5] - o.z) * inv.z;
+        if (inv.z < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    return true;
+}
+
+// Sphere::hit / MovingSphere::hit root selection (src/sphere.rs:44-81, 137-175). which = 0 near root, 1 far root.
+PT_DEV bool sphere_t(D3 center, double radius, D3 o, D3 d, double t_min, double t_max, double &t_out, int &which) {
+    D3 oc = o - center;
+    double a = dot(d, d);
+    double b = dot(oc, d);
+    double c = dot(oc, oc) - radius * radius;
+    double discriminant = b * b - a * c;
+    if (discriminant > 0.0) {
+        double root = sqrt(b * b - a * c);
+        double temp = (-b - root) / a;
+        if (temp < t_max && temp > t_min) {
+            t_out = temp;
+            which = 0;
+            return true;
+        }
+        temp = (-b + root) / a;
+        if (temp < t_max && temp > t_min) {
+            t_out = temp;
+            which = 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// AxisAlignedRect::hit acceptance (src/rect.rs:97-105); axis 0 = X, 1 = Y, 2 = Z (63-85).
+PT_DEV bool rect_t(double amin, double amax, double bmin, double bmax, double c, int axis, D3 o, D3 d, double t_min,
+                   double t_max, double &t_out) {
+    double t, a, b;
+    if (axis == 0) {
+        t = (c - o.x) / d.x;
+        if (t < t_min || t > t_max) return false;
+        a = o.y + t * d.y;
+        b = o.z + t * d.z;
+    } else if (axis == 1) {
+        t = (c - o.y) / d.y;
+        if (t < t_min || t > t_max) return false;
+        a = o.x + t * d.x;
+        b = o.z + t * d.z;
+    } else {
+        t = (c - o.z) / d.z;
+        if (t < t_min || t > t_max) return false;
+        a = o.x + t * d.x;
+        b = o.y + t * d.y;
+    }
+    if (a < amin || a > amax || b < bmin || b > bmax) return false;
+    t_out = t;
+    return true;
+}
+
+// Rect parameters of face k of AxisAlignedBox (src/axis_aligned_box.rs:17-22): +Z, -Z, +Y, -Y, +X, -X.
+PT_DEV void box_face(const double *pb, int k, double &amin, double &amax, double &bmin, double &bmax, double &c,
+                     int &axis) {
+    if (k < 2) {
+        amin = pb[0]; amax = pb[3]; bmin = pb[1]; bmax = pb[4]; axis = 2;
+        c = (k == 0) ? pb[5] : pb[2];
+    } else if (k < 4) {
+        amin = pb[0]; amax = pb[3]; bmin = pb[2]; bmax = pb[5]; axis = 1;
+        c = (k == 2) ? pb[4] : pb[1];
+    } else {
+        amin = pb[1]; amax = pb[4]; bmin = pb[2]; bmax = pb[5]; axis = 0;
+        c = (k == 4) ? pb[3] : pb[0];
+    }
+}
+// AxisAlignedBox::hit = HitableList::hit over its six faces with a shrinking t_max (src/hitable.rs:51-62).
+PT_DEV bool box_t(const double *pb, D3 o, D3 d, double t_min, double t_max, double &t_out, int &face) {
+    double closest = t_max;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double amin, amax, bmin, bmax, c, t;
+        int axis;
+        box_face(pb, k, amin, amax, bmin, bmax, c, axis);
+        if (rect_t(amin, amax, bmin, bmax, c, axis, o, d, t_min, closest, t)) {
+            closest = t;
+            face = k;
+            any = true;
+        }
+    }
+    t_out = closest;
+    return any;
+}
+
+PT_DEV D3 moving_center(const double *pd, const double *e, double time) { // src/sphere.rs:130-132
+    return d3(pd[0], pd[1], pd[2]) + ((time - pd[4]) / pd[5]) * d3(e[0], e[1], e[2]);
+}
+
+// One primitive op against a ray that is already in the op's frame; applies the op's own chain first.
+// `sub` is the near/far root for spheres and the face for boxes.
+PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, double time, double t_min, double t_max,
+                     double &t_out, int &sub) {
+    const int kind = op.kind & 0xff;
+    const int cc = (op.kind >> 16) & 0xff;
+    if (cc) apply_chain(sv.xforms, op.chain_start, cc, o, d);
+    sub = 0;
+    switch (kind) {
+    case OP_SPHERE:
+        return sphere_t(d3(op.d[0], op.d[1], op.d[2]), op.d[3], o, d, t_min, t_max, t_out, sub);
+    case OP_MSPHERE:
+        return sphere_t(moving_center(op.d, sv.leaves[op.leaf].e, time), op.d[3], o, d, t_min, t_max, t_out, sub);
+    case OP_RECT:
+        return rect_t(op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], (op.kind >> 8) & 3, o, d, t_min, t_max, t_out);
+    case OP_BOXPRIM:
+        return box_t(op.d, o, d, t_min, t_max, t_out, sub);
+    default:
+        return false;
+    }
+}
+
+// ConstantMedium::hit (src/volume.rs:24-65). The ray is in the medium's frame once the op's chain is applied.
+PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, double time, double t_min, double t_max,
+                       uint64_t pkey, uint32_t depth, double &t_out) {
+    const int cc = (op.kind >> 16) & 0xff;
+    if (cc) apply_chain(sv.xforms, op.chain_start, cc, o, d);
+    const DevOp &bop = sv.ops[op.skip];
+    double t1, t2;
+    int sub;
+    if (!prim_hit(sv, bop, o, d, time, -kF64Max, kF64Max, t1, sub)) return false;
+    if (!prim_hit(sv, bop, o, d, time, t1 + 0.0001, kF64Max, t2, sub)) return false;
+    t1 = fmax(t1, t_min);
+    t2 = fmin(t2, t_max);
+    if (t1 >= t2) return false;
+    double ray_length = length(d);
+    double distance_inside_boundary = (t2 - t1) * ray_length;
+    double xi = medium_draw(pkey, depth, sv.leaves[op.leaf].prim[0]);
+    double hit_distance = -(1.0 / op.d[0]) * log(xi);
+    if (hit_distance < distance_inside_boundary) {
+        t_out = t1 + hit_distance / ray_length;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------- finalisation --
+struct HitRec { // src/hitable.rs:5-12
+    double t, u, v;
+    D3 p, n;
+    int32_t mat;
+    int32_t prim;
+};
+
+PT_DEV void get_sphere_uv(D3 p, double &u, double &v) { // src/sphere.rs:8-14
+    double phi = atan2(p.z, p.x);
+    double theta = asin(p.y);
+    u = 1.0 - (phi + kPi) / (kPi * 2.0);
+    v = (theta + kFracPi2) / kPi;
+}
+
+// Rebuilds the HitRecord of the closest hit from (world ray, t, leaf, sub): the leaf's full chain takes the
+// ray to the primitive's space with the same sequence of operations the traversal used, the record is built
+// there as the primitive's hit() does, then carried back out through the wrappers in reverse.
+template <bool NEED_UV>
+PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double t, int leaf_id, int sub) {
+    const DevLeaf lf = sv.leaves[leaf_id];
+    apply_chain(sv.xforms, lf.full_start, lf.full_count, o, d);
+    HitRec r;
+    r.t = t;
+    r.u = 0.0;
+    r.v = 0.0;
+    r.mat = lf.material;
+    r.prim = lf.prim[0];
+    const DevOp &op = sv.ops[lf.op];
+    D3 point = o + (d * t); // Ray::point_at_parameter, src/math/ray.rs:30-32
+    r.p = point;
+    switch (lf.kind) {
+    case OP_SPHERE: {
+        D3 c = d3(op.d[0], op.d[1], op.d[2]);
+        if (NEED_UV) {
+            if (sub == 0) get_sphere_uv((c - point) / op.d[3], r.u, r.v); // sphere.rs:56
+            else get_sphere_uv(c - point, r.u, r.v);                      // sphere.rs:69
+        }
+        r.n = (point - c) / op.d[3];
+        break;
+    }
+    case OP_MSPHERE: {
+        D3 c = moving_center(op.d, lf.e, time);
+        if (NEED_UV) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
+        r.n = (point - c) / op.d[3];
+        break;
+    }
+    case OP_RECT:
+    case OP_BOXPRIM: {
+        double amin, amax, bmin, bmax, c;
+        int axis;
+        if (lf.kind == OP_RECT) {
+            amin = op.d[0]; amax = op.d[1]; bmin = op.d[2]; bmax = op.d[3]; c = op.d[4];
+            axis = lf.axis;
+        } else {
+            box_face(op.d, sub, amin, amax, bmin, bmax, c, axis);
+            r.prim = lf.prim[sub];
+        }
+        double a, b;
+        if (axis == 0) { a = o.y + t * d.y; b = o.z + t * d.z; }
+        else if (axis == 1) { a = o.x + t * d.x; b = o.z + t * d.z; }
+        else { a = o.x + t * d.x; b = o.y + t * d.y; }
+        r.u = (a - amin) / (amax - amin); // rect.rs:46-47,108-109
+        r.v = (b - bmin) / (bmax - bmin);
+        r.n = axis == 0 ? d3(1.0, 0.0, 0.0) : (axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
+        if (lf.kind == OP_BOXPRIM && (sub & 1)) r.n = -r.n; // faces 1, 3, 5 are wrapped in FlipNormals
+        break;
+    }
+    default: // OP_MEDIUM, volume.rs:51-59
+        r.n = d3(1.0, 0.0, 0.0);
+        break;
+    }
+    for (int k = lf.full_count - 1; k >= 0; --k) unxform_hit(sv.xforms[lf.full_start + k], r.p, r.n);
+    return r;
+}
+
+// -------------------------------------------------------------- textures --
+PT_DEV double perlin_noise(const pt_perlin *t, D3 p) { // src/math/noise.rs:26-44, 89-113
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    // Rust's `as i32` saturates and maps NaN to 0
+    int32_t i = (fx != fx) ? 0 : (fx >= 2147483647.0 ? 2147483647 : (fx <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)fx));
+    int32_t j = (fy != fy) ? 0 : (fy >= 2147483647.0 ? 2147483647 : (fy <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)fy));
+    int32_t k = (fz != fz) ? 0 : (fz >= 2147483647.0 ? 2147483647 : (fz <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)fz));
+    double u = p.x - (double)i, v = p.y - (double)j, w = p.z - (double)k;
+    double uu = u * u * (3.0 - 2.0 * u);
+    double vv = v * v * (3.0 - 2.0 * v);
+    double ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                int32_t ix = t->perm_x[((uint32_t)i + (uint32_t)di) & 255u] ^ t->perm_y[((uint32_t)j + (uint32_t)dj) & 255u] ^
+                             t->perm_z[((uint32_t)k + (uint32_t)dk) & 255u];
+                D3 c = d3(t->ranvec[ix][0], t->ranvec[ix][1], t->ranvec[ix][2]);
+                double fi = di, fj = dj, fk = dk;
+                D3 weight_v = d3(u - fi, v - fj, w - fk);
+                accum += (fi * uu + (1.0 - fi) * (1.0 - uu)) * (fj * vv + (1.0 - fj) * (1.0 - vv)) *
+                         (fk * ww + (1.0 - fk) * (1.0 - ww)) * dot(c, weight_v);
+            }
+    return accum;
+}
+PT_DEV double perlin_turb(const pt_perlin *t, D3 p, int depth) { // src/math/noise.rs:115-126
+    double accum = 0.0;
+    D3 temp_p = p;
+    double weight = 1.0;
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * perlin_noise(t, temp_p);
+        weight *= 0.5;
+        temp_p = temp_p * 2.0;
+    }
+    return fabs(accum);
+}
+PT_DEV double clamp_ref(double a, double lo, double hi) { // src/math/mod.rs:22-26
+    double b = a > hi ? hi : a;
+    b = b < lo ? lo : b;
+    return b;
+}
+// Texture::value (src/texture.rs:24-28, 47-56, 70-75, 101-114). Checker children are resolved iteratively.
+PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) {
+    const pt_texture *t = &sv.textures[tex];
+    for (int guard = 0; guard < 16 && t->kind == PT_T_CHECKER; ++guard) {
+        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+        t = &sv.textures[sines < 0.0 ? t->odd : t->even];
+    }
+    if (t->kind == PT_T_CONSTANT) return d3(t->colour[0], t->colour[1], t->colour[2]);
+    if (t->kind == PT_T_NOISE) {
+        double noise = t->scale * p.z + 10.0 * perlin_turb(sv.perlin, p, 7);
+        double g = 1.0 * 0.5 * (1.0 + sin(noise));
+        return d3(g, g, g);
+    }
+    if (t->kind == PT_T_IMAGE) {
+        double wf = (double)t->width, hf = (double)t->height;
+        double ci = clamp_ref(u * wf, 0.0, wf - 1.0);
+        double cj = clamp_ref(v * hf - 0.001, 0.0, hf - 1.0);
+        uint64_t ii = (ci > 0.0) ? (uint64_t)ci : 0; // `as usize`: NaN -> 0
+        uint64_t jj = (cj > 0.0) ? (uint64_t)cj : 0;
+        const uint8_t *px = sv.texels + t->texel_offset + 3 * ii + 3 * (uint64_t)t->width * jj;
+        return d3((double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0);
+    }
+    return d3(0.0, 0.0, 0.0);
+}
+
+// -------------------------------------------------------------- samplers --
+struct Onb { // src/onb.rs:18-37
+    D3 u, v, w;
+};
+PT_DEV Onb onb_from_w(D3 n) {
+    D3 w = unit_vector(n);
+    D3 a = fabs(w.x) > 0.9 ? d3(0.0, 1.0, 0.0) : d3(1.0, 0.0, 0.0);
+    D3 v = unit_vector(cross(w, a));
+    D3 u = cross(w, v);
+    return Onb{u, v, w};
+}
+PT_DEV D3 onb_local(const Onb &b, D3 a) { return b.u * a.x + b.v * a.y + b.w * a.z; }
+
+PT_DEV D3 random_cosine_direction(Rng &g) { // src/material.rs:10-19
+    double r1 = g.next();
+    double r2 = g.next();
+    double z = sqrt(1.0 - r2);
+    double phi = 2.0 * kPi * r1;
+    double r2_sqrt = sqrt(r2);
+    double x = cos(phi) * r2_sqrt;
+    double y = sin(phi) * r2_sqrt;
+    return d3(x, y, z);
+}
+PT_DEV D3 random_in_unit_sphere(Rng &g) { // src/material.rs:21-31
+    D3 p;
+    for (;;) {
+        double a = g.next();
+        double b = g.next();
+        double c = g.next();
+        p = 2.0 * d3(a, b, c) - d3(1.0, 1.0, 1.0);
+        if (squared_length(p) < 1.0) break;
+    }
+    return p;
+}
+PT_DEV D3 random_in_unit_disk(Rng &g) { // src/camera.rs:221-228
+    double a = g.next();
+    double b = g.next();
+    D3 nv = d3(a, b, 0.0) * 2.0 - d3(1.0, 1.0, 0.0);
+    while (dot(nv, nv) >= 1.0) {
+        a = g.next();
+        b = g.next();
+        nv = d3(a, b, 0.0) * 2.0 - d3(1.0, 1.0, 0.0);
+    }
+    return nv;
+}
+PT_DEV D3 random_to_sphere(Rng &g, double radius, double distance_squared) { // src/sphere.rs:16-25
+    double r1 = g.next();
+    double r2 = g.next();
+    double z = 1.0 + r2 * (sqrt(1.0 - radius * radius / distance_squared) - 1.0);
+    double phi = 2.0 * kPi * r1;
+    double c = sqrt(1.0 - z * z);
+    double x = cos(phi) * c;
+    double y = sin(phi) * c;
+    return d3(x, y, z);
+}
+
+// ---------------------------------------------------------------- lights --
+// Hitable::pdf_value of one light shape (src/sphere.rs:87-95, src/rect.rs:124-133, default src/hitable.rs:30-32).
+PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3 direction) {
+    if (l.kind == LIGHT_SPHERE) {
+        double t;
+        int which;
+        D3 c = d3(l.d[0], l.d[1], l.d[2]);
+        if (sphere_t(c, l.d[3], origin, direction, 0.001, kF64Max, t, which)) {
+            double cos_theta_max = sqrt(1.0 - l.d[3] * l.d[3] / squared_length(c - origin));
+            double solid_angle = 2.0 * kPi * (1.0 - cos_theta_max);
+            return 1.0 / solid_angle;
+        }
+        return 0.0;
+    }
+    if (l.kind == LIGHT_RECT) {
+        double t;
+        if (rect_t(l.d[0], l.d[1], l.d[2], l.d[3], l.d[4], l.axis, origin, direction, 0.001, kF64Max, t)) {
+            double area = (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]);
+            double v_sq_length = squared_length(direction);
+            double distance_sq = t * t * v_sq_length;
+            D3 normal = l.axis == 0 ? d3(1.0, 0.0, 0.0) : (l.axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
+            double cosine = fabs(dot(direction, normal) / sqrt(v_sq_length));
+            return distance_sq / (cosine * area);
+        }
+        return 0.0;
+    }
+    return 0.0;
+}
+// Hitable::random of one light shape (src/sphere.rs:96-101, src/rect.rs:135-144, default src/hitable.rs:33-35).
+PT_DEV D3 light_random(const DevLight &l, Rng &g, D3 origin) {
+    if (l.kind == LIGHT_SPHERE) {
+        D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
+        double distance_sq = squared_length(direction);
+        Onb uvw = onb_from_w(direction);
+        return onb_local(uvw, random_to_sphere(g, l.d[3], distance_sq));
+    }
+    if (l.kind == LIGHT_RECT) {
+        double random_a = l.d[0] + g.next() * (l.d[1] - l.d[0]);
+        double random_b = l.d[2] + g.next() * (l.d[3] - l.d[2]);
+        D3 p = l.axis == 0 ? d3(l.d[4], random_a, random_b)
+                           : (l.axis == 1 ? d3(random_a, l.d[4], random_b) : d3(random_a, random_b, l.d[4]));
+        return p - origin;
+    }
+    return d3(1.0, 0.0, 0.0);
+}
+// HitableList::pdf_value / random over the light list (src/hitable.rs:66-77).
+PT_DEV double lights_pdf_value(const SceneView &sv, D3 origin, D3 direction) {
+    double weight = 1.0 / (double)sv.n_lights;
+    double sum = 0.0;
+    for (int k = 0; k < sv.n_lights; ++k) sum += weight * light_pdf_value(sv.lights[k], origin, direction);
+    return sum;
+}
+PT_DEV D3 lights_random(const SceneView &sv, Rng &g, D3 origin) {
+    double x = (double)sv.n_lights * g.next();
+    int index = (int)x;
+    return light_random(sv.lights[index], g, origin);
+}
+
+// ------------------------------------------------------------- materials --
+PT_DEV D3 reflect(D3 v, D3 n) { return v - (2.0 * dot(v, n) * n); } // src/material.rs:50-52
+PT_DEV bool refract(D3 v, D3 n, double ni_over_nt, D3 &refracted) { // src/material.rs:54-64
+    D3 uv = unit_vector(v);
+    double dt = dot(uv, n);
+    double discriminant = 1.0 - ni_over_nt * ni_over_nt * (1.0 - dt * dt);
+    if (discriminant > 0.0) {
+        refracted = ni_over_nt * (uv - n * dt) - n * sqrt(discriminant);
+        return true;
+    }
+    return false;
+}
+PT_DEV double schlick(double cosine, double ref_idx) { // src/material.rs:66-70
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0 - r0) * pow(1.0 - cosine, 5.0);
+}
+
+// Material::emitted (src/material.rs:145-147 default, 303-305 Lambertian, 325-331 DiffuseLight).
+PT_DEV D3 emitted(const SceneView &sv, const pt_material &m, D3 ray_d, const HitRec &rec) {
+    if (m.kind == PT_M_LAMBERTIAN) {
+        if (m.emissive > 0.0) return texture_value(sv, m.texture, rec.u, rec.v, rec.p) * m.emissive;
+        return d3(0.0, 0.0, 0.0);
+    }
+    if (m.kind == PT_M_DIFFUSE_LIGHT) {
+        if (dot(rec.n, ray_d) < 0.0) return texture_value(sv, m.texture, rec.u, rec.v, rec.p);
+        return d3(0.0, 0.0, 0.0);
+    }
+    return d3(0.0, 0.0, 0.0);
+}
+
+} // namespace ptdev

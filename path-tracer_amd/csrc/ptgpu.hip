@@ -1,0 +1,1007 @@
+// Wavefront path tracer for gfx950 (MI355X) and its extern "C" entry points (include/ptgpu.h).
+//
+// The per-pixel recursion of TraceSceneBatchJob::trace / color (src/trace.rs:117-234) becomes four stages over
+// queues of path states held in HBM as structure-of-arrays:
+//   raygen   camera samples -> ray queue                      (src/trace.rs:152-158, src/camera.rs:53-59)
+//   extend   closest hit of every queued ray                  (Hitable::hit on SceneState.world, src/bvh.rs:74-99)
+//   shade    emitted / scatter / light sampling, next ray     (src/trace.rs:205-226, src/material.rs)
+//            + compaction of surviving paths into the next queue (wave64 ballot + LDS-staged block offsets)
+//   resolve  per-pixel mean in sample order -> f32 RGBA image (src/trace.rs:166-182)
+// One pass traces `paths in flight` paths to completion: raygen, then (extend, shade) once per bounce.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "flatten.h"
+#include "pt_device.h"
+
+using namespace ptdev;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr uint32_t kDefaultPathsInFlight = 1u << 22;
+constexpr int kMaxDepthSlots = 1024; // counts[] entries; max_depth is capped at kMaxDepthSlots - 2
+
+// ------------------------------------------------------------------------------------------------------------
+// Path-state queues (structure of arrays, one entry per in-flight ray)
+// ------------------------------------------------------------------------------------------------------------
+struct Queue {
+    double *ox, *oy, *oz, *dx, *dy, *dz, *tm; // ray (src/math/ray.rs:3-7)
+    double *bx, *by, *bz;                     // path throughput
+    uint32_t *pid;                            // path id within the pass
+    uint32_t *rn;                             // RNG draws consumed so far
+};
+
+struct CameraDev { // derived fields of Camera::new (src/camera.rs:25-51)
+    D3 origin, lower_left_corner, horizontal, vertical, u, v;
+    double time0, time1, lens_radius;
+};
+
+struct PassParams {
+    uint64_t seed;
+    uint32_t frame;
+    uint32_t width, height; // image size
+    uint32_t cx0, cy0;      // first pixel of the chunk
+    uint32_t cw;            // chunk width in pixels (== tile width)
+    uint32_t cpix;          // pixels in the chunk
+    uint32_t s_base;        // first sample index of this pass
+    uint32_t s_count;       // samples per pixel in this pass
+    uint32_t spp;           // samples per pixel of the whole render call
+    uint32_t max_depth;
+    uint32_t mode;
+    uint32_t first_pass, last_pass;
+};
+
+struct TraversalCounters {
+    unsigned long long node_visits, prim_tests;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Compaction: one slot per surviving lane. Wave64 ballot + popcount give the rank inside the wave, the four
+// wave totals are staged in LDS, and one atomic per workgroup reserves the block's range in the output queue.
+// Every thread of the block must call this the same number of times.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *out_count, uint32_t *lds /* kWavesPerBlock + 1 */) {
+    const unsigned long long ballot = __ballot(alive);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            uint32_t c = lds[w];
+            lds[w] = total; // exclusive prefix of the wave totals
+            total += c;
+        }
+        lds[kWavesPerBlock] = total ? atomicAdd(out_count, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = lds[kWavesPerBlock] + lds[wave] + rank;
+    __syncthreads(); // lds is reused by the next call
+    return slot;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// raygen
+// ------------------------------------------------------------------------------------------------------------
+template <bool REALTIME>
+__global__ __launch_bounds__(kBlock) void k_raygen(Queue q, uint64_t *keys, double *lx, double *ly, double *lz,
+                                                   CameraDev cam, PassParams pp, uint32_t *counts) {
+    __shared__ uint32_t lds[kWavesPerBlock + 1];
+    const uint32_t n = pp.cpix * pp.s_count;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t pid = base + threadIdx.x;
+        bool alive = pid < n;
+        uint32_t i = 0, j = 0, s = 0;
+        uint64_t pixel = 0;
+        if (alive) {
+            const uint32_t p = pid % pp.cpix;
+            s = pid / pp.cpix;
+            i = pp.cx0 + p % pp.cw;
+            j = pp.cy0 + p / pp.cw;
+            pixel = (uint64_t)j * pp.width + i;
+            if (REALTIME) alive = !(pixel_skip_draw(pp.seed, pp.frame, pixel) < 0.8); // src/trace.rs:144
+        }
+        uint32_t slot = pid;
+        if (REALTIME) slot = compact_slot(alive, &counts[0], lds);
+        if (alive) {
+            Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
+            // src/trace.rs:153-156
+            double random = g.next();
+            const double u = ((double)i + random) / (double)pp.width;
+            random = g.next();
+            const double v = ((double)j + random) / (double)pp.height;
+            // Camera::get_ray, src/camera.rs:53-59
+            D3 rd = random_in_unit_disk(g) * cam.lens_radius;
+            D3 offset = cam.u * rd.x + cam.v * rd.y;
+            const double time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+            D3 direction = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+            D3 origin = cam.origin + offset;
+            q.ox[slot] = origin.x; q.oy[slot] = origin.y; q.oz[slot] = origin.z;
+            q.dx[slot] = direction.x; q.dy[slot] = direction.y; q.dz[slot] = direction.z;
+            q.tm[slot] = time;
+            q.bx[slot] = 1.0; q.by[slot] = 1.0; q.bz[slot] = 1.0;
+            q.pid[slot] = pid;
+            q.rn[slot] = g.n;
+            keys[pid] = g.key;
+        }
+        if (pid < n) { // radiance accumulator of the path, also for skipped pixels
+            lx[pid] = 0.0; ly[pid] = 0.0; lz[pid] = 0.0;
+        }
+    }
+    if (!REALTIME && blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// extend: threaded, stackless traversal of the op stream, one ray per lane
+// ------------------------------------------------------------------------------------------------------------
+// KEYMODE 0: the path's key is keys[pid[i]] (render); 1: intersect_key(medium_seed, i) (pt_intersect)
+template <int KEYMODE, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(Queue q, const uint32_t *count_ptr, SceneView sv, double t_min,
+                                                   double t_max_in, const uint64_t *keys, uint64_t medium_seed,
+                                                   uint32_t depth, double *hit_t, int32_t *hit_id,
+                                                   TraversalCounters *counters) {
+    const uint32_t n = *count_ptr;
+    unsigned long long my_nodes = 0, my_prims = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const D3 wo = d3(q.ox[i], q.oy[i], q.oz[i]);
+        const D3 wd = d3(q.dx[i], q.dy[i], q.dz[i]);
+        const double time = q.tm[i];
+        uint64_t pkey = 0;
+        if (sv.has_medium) pkey = (KEYMODE == 0) ? keys[q.pid[i]] : intersect_key(medium_seed, i);
+
+        D3 o = wo, d = wd;
+        D3 inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        double closest = t_max_in;
+        int32_t best = -1;
+        int32_t cur = 0;
+        const int32_t end = sv.n_traversal_ops;
+        while (cur < end) {
+            const DevOp *op = &sv.ops[cur];
+            const int32_t kword = op->kind;
+            const int kind = kword & 0xff;
+            if (kind == OP_BOX) {
+                if (COUNT) ++my_nodes;
+                if (aabb_hit(op->d, o, inv, t_min, closest)) cur += 1;
+                else cur = op->skip;
+                continue;
+            }
+            if (kind == OP_ENTER) {
+                apply_chain(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
+                inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            } else if (kind == OP_EXIT) {
+                o = wo;
+                d = wd;
+                apply_chain(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
+                inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            } else if (kind == OP_MEDIUM) {
+                if (COUNT) my_prims += 2;
+                double t;
+                if (medium_hit(sv, *op, o, d, time, t_min, closest, pkey, depth, t)) {
+                    closest = t;
+                    best = op->leaf;
+                }
+            } else {
+                if (COUNT) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
+                double t;
+                int sub;
+                if (prim_hit(sv, *op, o, d, time, t_min, closest, t, sub)) {
+                    closest = t;
+                    best = op->leaf | (sub << 28);
+                }
+            }
+            cur += 1;
+        }
+        hit_t[i] = closest;
+        hit_id[i] = best;
+    }
+    if (COUNT) {
+        atomicAdd(&counters->node_visits, my_nodes);
+        atomicAdd(&counters->prim_tests, my_prims);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// shade + compaction
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz, uint32_t pid, D3 c) {
+    // Adding an exact zero changes nothing; a NaN compares unequal to zero and is added, which keeps the
+    // reference's NaN propagation (0 * x / 0 in src/trace.rs:217-220).
+    if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) {
+        lx[pid] += c.x;
+        ly[pid] += c.y;
+        lz[pid] += c.z;
+    }
+}
+
+template <bool NEED_UV>
+__global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint32_t *n_in, uint32_t *n_out,
+                                                  SceneView sv, const double *hit_t, const int32_t *hit_id,
+                                                  const uint64_t *keys, double *lx, double *ly, double *lz,
+                                                  uint32_t depth, uint32_t max_depth) {
+    __shared__ uint32_t lds[kWavesPerBlock + 1];
+    const uint32_t n = *n_in;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
+        double time = 0.0;
+        uint32_t pid = 0, rn = 0;
+        if (i < n) {
+            const D3 o = d3(qi.ox[i], qi.oy[i], qi.oz[i]);
+            const D3 d = d3(qi.dx[i], qi.dy[i], qi.dz[i]);
+            time = qi.tm[i];
+            const D3 beta = d3(qi.bx[i], qi.by[i], qi.bz[i]);
+            pid = qi.pid[i];
+            const int32_t id = hit_id[i];
+            if (id < 0) {
+                // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
+                add_radiance(lx, ly, lz, pid, beta * 0.0);
+            } else {
+                Rng g{keys[pid], qi.rn[i]};
+                const HitRec rec = finalize_hit<NEED_UV>(sv, o, d, time, hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
+                const pt_material m = sv.materials[rec.mat];
+                const D3 emissive = emitted(sv, m, d, rec);
+                bool done = true;
+                if (depth < max_depth) {
+                    if (m.kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
+                        D3 outward_normal;
+                        D3 reflected = reflect(d, rec.n);
+                        double ni_over_nt, reflect_prob, cosine;
+                        D3 refracted = d3(0.0, 0.0, 0.0);
+                        if (dot(d, rec.n) > 0.0) {
+                            outward_normal = -rec.n;
+                            ni_over_nt = m.ref_idx;
+                            cosine = m.ref_idx * dot(d, rec.n) / length(d);
+                        } else {
+                            outward_normal = rec.n;
+                            ni_over_nt = 1.0 / m.ref_idx;
+                            cosine = -dot(d, rec.n) / length(d);
+                        }
+                        if (refract(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick(cosine, m.ref_idx);
+                        else reflect_prob = 1.0;
+                        nd = (g.next() < reflect_prob) ? reflected : refracted;
+                        no = rec.p;
+                        nbeta = beta * d3(1.0, 1.0, 1.0); // specular: albedo * color(next), no emission (trace.rs:209-211)
+                        done = false;
+                    } else if (m.kind == PT_M_METAL) { // src/material.rs:230-241
+                        D3 reflected = reflect(unit_vector(d), rec.n);
+                        nd = reflected + m.fuzz * random_in_unit_sphere(g);
+                        no = rec.p;
+                        nbeta = beta * d3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                        done = false;
+                    } else if (m.kind == PT_M_LAMBERTIAN || m.kind == PT_M_ISOTROPIC) {
+                        const bool lambert = m.kind == PT_M_LAMBERTIAN;
+                        // scatter(): src/material.rs:289-301 (Lambertian), 347-351 (Isotropic draws a sphere sample it never uses)
+                        if (!lambert) (void)random_in_unit_sphere(g);
+                        const D3 albedo = texture_value(sv, m.texture, rec.u, rec.v, rec.p);
+                        Onb uvw;
+                        if (lambert) uvw = onb_from_w(rec.n);
+                        // MixturePDF::generate, src/material.rs:427-433
+                        D3 dir;
+                        if (g.next() < 0.5) dir = lights_random(sv, g, rec.p);
+                        else dir = lambert ? onb_local(uvw, random_cosine_direction(g)) : d3(0.0, 0.0, 0.0);
+                        // MixturePDF::value, src/material.rs:424-426
+                        double own = 0.0;
+                        if (lambert) { // CosinePDF::value, src/material.rs:375-382
+                            double cosine = dot(unit_vector(dir), uvw.w);
+                            own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
+                        }
+                        const double pdf_val = 0.5 * lights_pdf_value(sv, rec.p, dir) + 0.5 * own;
+                        double spdf = 0.0;
+                        if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
+                            double cosine = dot(rec.n, unit_vector(dir));
+                            spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
+                        }
+                        // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
+                        add_radiance(lx, ly, lz, pid, beta * emissive);
+                        nbeta = beta * (albedo * spdf) / pdf_val;
+                        no = rec.p;
+                        nd = dir;
+                        done = false;
+                    }
+                }
+                if (done) add_radiance(lx, ly, lz, pid, beta * emissive); // src/trace.rs:225
+                alive = !done;
+                rn = g.n;
+            }
+        }
+        const uint32_t slot = compact_slot(alive, n_out, lds);
+        if (alive) {
+            qo.ox[slot] = no.x; qo.oy[slot] = no.y; qo.oz[slot] = no.z;
+            qo.dx[slot] = nd.x; qo.dy[slot] = nd.y; qo.dz[slot] = nd.z;
+            qo.tm[slot] = time;
+            qo.bx[slot] = nbeta.x; qo.by[slot] = nbeta.y; qo.bz[slot] = nbeta.z;
+            qo.pid[slot] = pid;
+            qo.rn[slot] = rn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// resolve: per-pixel sum in sample order, then the write of src/trace.rs:166-182
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const double *ly, const double *lz, double *ax,
+                                                    double *ay, double *az, float *image, uint32_t *frames_per_pixel,
+                                                    PassParams pp, const uint32_t *counts, unsigned long long *stats) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < pp.cpix; p += gridDim.x * kBlock) {
+        double sx = pp.first_pass ? 0.0 : ax[p];
+        double sy = pp.first_pass ? 0.0 : ay[p];
+        double sz = pp.first_pass ? 0.0 : az[p];
+        for (uint32_t s = 0; s < pp.s_count; ++s) { // pixel_colour += color(...) in sample order
+            const uint32_t pid = s * pp.cpix + p;
+            sx += lx[pid];
+            sy += ly[pid];
+            sz += lz[pid];
+        }
+        if (!pp.last_pass) {
+            ax[p] = sx; ay[p] = sy; az[p] = sz;
+            continue;
+        }
+        const uint32_t i = pp.cx0 + p % pp.cw;
+        const uint32_t j = pp.cy0 + p / pp.cw;
+        const uint64_t pixel = (uint64_t)j * pp.width + i;
+        float *px = image + pixel * 4;
+        const double ns = (double)pp.spp;
+        const double cx = sx / ns, cy = sy / ns, cz = sz / ns; // src/trace.rs:166
+        if (pp.mode == PT_MODE_REALTIME) {
+            if (pixel_skip_draw(pp.seed, pp.frame, pixel) < 0.8) continue; // src/trace.rs:144-146
+            uint32_t c = frames_per_pixel[pixel];
+            c += (c <= 1000u) ? 1u : 0u; // src/trace.rs:149
+            frames_per_pixel[pixel] = c;
+            const float weight = 1.0f / (float)c; // src/trace.rs:171-177
+            const float one_minus_weight = 1.0f - weight;
+            px[0] = (float)cx * weight + px[0] * one_minus_weight;
+            px[1] = (float)cy * weight + px[1] * one_minus_weight;
+            px[2] = (float)cz * weight + px[2] * one_minus_weight;
+        } else {
+            px[0] = (float)cx; // src/trace.rs:179-181
+            px[1] = (float)cy;
+            px[2] = (float)cz;
+        }
+        if (px[0] != px[0] || px[1] != px[1] || px[2] != px[2]) atomicAdd(&stats[1], 1ull);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long seg = 0;
+        for (uint32_t k = 0; k <= pp.max_depth; ++k) seg += counts[k];
+        atomicAdd(&stats[0], seg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pt_intersect helpers
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_load_rays(const pt_ray *rays, uint32_t n, Queue q) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const pt_ray r = rays[i];
+        q.ox[i] = r.origin[0]; q.oy[i] = r.origin[1]; q.oz[i] = r.origin[2];
+        q.dx[i] = r.direction[0]; q.dy[i] = r.direction[1]; q.dz[i] = r.direction[2];
+        q.tm[i] = r.time;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, SceneView sv, const double *hit_t,
+                                                       const int32_t *hit_id, pt_hit *out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        pt_hit h;
+        const int32_t id = hit_id[i];
+        if (id < 0) {
+            h.t = 0.0; h.u = 0.0; h.v = 0.0;
+            h.p[0] = h.p[1] = h.p[2] = 0.0;
+            h.normal[0] = h.normal[1] = h.normal[2] = 0.0;
+            h.prim = -1;
+            h.material = -1;
+        } else {
+            const HitRec rec = finalize_hit<true>(sv, d3(q.ox[i], q.oy[i], q.oz[i]), d3(q.dx[i], q.dy[i], q.dz[i]),
+                                                  q.tm[i], hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
+            h.t = rec.t; h.u = rec.u; h.v = rec.v;
+            h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
+            h.normal[0] = rec.n.x; h.normal[1] = rec.n.y; h.normal[2] = rec.n.z;
+            h.prim = rec.prim;
+            h.material = rec.mat;
+        }
+        out[i] = h;
+    }
+}
+
+} // namespace
+
+// ================================================================================================================
+// Context
+// ================================================================================================================
+
+struct pt_ctx {
+    int device = 0;
+    uint64_t seed = 0;
+    uint32_t flags = 0;
+    uint32_t capacity = 0; // paths in flight
+    hipStream_t stream = nullptr;
+    std::string error;
+    int n_cu = 256;
+
+    // scene
+    bool have_scene = false, have_camera = false;
+    FlatScene flat;
+    SceneView view{};
+    bool need_uv = false;
+    void *d_ops = nullptr, *d_xforms = nullptr, *d_leaves = nullptr, *d_lights = nullptr, *d_materials = nullptr,
+         *d_textures = nullptr, *d_texels = nullptr, *d_perlin = nullptr;
+    CameraDev cam{};
+
+    // path state
+    void *d_pool = nullptr; // one allocation carved into the arrays below
+    Queue q[2]{};
+    uint64_t *d_keys = nullptr;
+    double *d_l[3] = {nullptr, nullptr, nullptr};
+    double *d_hit_t = nullptr;
+    int32_t *d_hit_id = nullptr;
+    uint32_t *d_counts = nullptr;
+    unsigned long long *d_stats = nullptr; // [0] segments, [1] nan pixels
+    TraversalCounters *d_trav = nullptr;
+
+    // image
+    uint32_t width = 0, height = 0;
+    float *d_image = nullptr;
+    bool image_external = false;
+    float *d_image_owned = nullptr;
+    uint32_t *d_frames = nullptr;
+    double *d_acc[3] = {nullptr, nullptr, nullptr};
+    size_t acc_capacity = 0;
+
+    // profiling
+    pt_stats stats{};
+    std::vector<hipEvent_t> events;
+    uint32_t profile_period = 8;
+    uint64_t pass_counter = 0;
+    std::vector<uint32_t> h_counts;
+};
+
+namespace {
+
+int set_error(pt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                        \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                   \
+            return set_error(ctx, e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP,                   \
+                             std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
+        }                                                                                                         \
+    } while (0)
+
+template <typename T> int upload(pt_ctx *ctx, void **dst, const T *src, size_t count) {
+    if (*dst) {
+        (void)hipFree(*dst);
+        *dst = nullptr;
+    }
+    if (count == 0) return PT_OK;
+    HIP_TRY(ctx, hipMalloc(dst, count * sizeof(T)));
+    HIP_TRY(ctx, hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int grid_for(const pt_ctx *ctx, uint64_t n) {
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    uint64_t cap = (uint64_t)ctx->n_cu * 8; // 8 workgroups of 256 per CU = the 32-wave limit
+    if (blocks < 1) blocks = 1;
+    return (int)std::min(blocks, cap);
+}
+
+int alloc_path_state(pt_ctx *ctx) {
+    const size_t n = ctx->capacity;
+    // 2 queues x (10 f64 + 2 u32) + keys + 3 f64 radiance + hit (f64 + i32)
+    const size_t per_path = 2 * (10 * 8 + 2 * 4) + 8 + 3 * 8 + 8 + 4;
+    const size_t n_arrays = 2 * 12 + 1 + 3 + 2;
+    const size_t bytes = n * per_path + n_arrays * 256; // every array starts on a 256-byte boundary
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pool, bytes));
+    char *p = (char *)ctx->d_pool;
+    auto take = [&](size_t sz) {
+        char *r = p;
+        p += (sz + 255) & ~(size_t)255;
+        return (void *)r;
+    };
+    for (int k = 0; k < 2; ++k) {
+        Queue &q = ctx->q[k];
+        q.ox = (double *)take(n * 8); q.oy = (double *)take(n * 8); q.oz = (double *)take(n * 8);
+        q.dx = (double *)take(n * 8); q.dy = (double *)take(n * 8); q.dz = (double *)take(n * 8);
+        q.tm = (double *)take(n * 8);
+        q.bx = (double *)take(n * 8); q.by = (double *)take(n * 8); q.bz = (double *)take(n * 8);
+        q.pid = (uint32_t *)take(n * 4);
+        q.rn = (uint32_t *)take(n * 4);
+    }
+    ctx->d_keys = (uint64_t *)take(n * 8);
+    for (int k = 0; k < 3; ++k) ctx->d_l[k] = (double *)take(n * 8);
+    ctx->d_hit_t = (double *)take(n * 8);
+    ctx->d_hit_id = (int32_t *)take(n * 4);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_counts, kMaxDepthSlots * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stats, 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_trav, sizeof(TraversalCounters)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trav, 0, sizeof(TraversalCounters), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int ensure_image(pt_ctx *ctx, uint32_t w, uint32_t h) {
+    if (ctx->image_external) {
+        if (w != ctx->width || h != ctx->height)
+            return set_error(ctx, PT_ERR_INVALID_ARG, "render size differs from the bound image");
+    } else if (!ctx->d_image_owned || w != ctx->width || h != ctx->height) {
+        if (ctx->d_image_owned) (void)hipFree(ctx->d_image_owned);
+        ctx->d_image_owned = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_image_owned, (size_t)w * h * 4 * sizeof(float)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_image_owned, 0, (size_t)w * h * 4 * sizeof(float), ctx->stream));
+        ctx->d_image = ctx->d_image_owned;
+        ctx->width = w;
+        ctx->height = h;
+        if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+        ctx->d_frames = nullptr;
+    }
+    if (!ctx->d_frames) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames, (size_t)w * h * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_frames, 0, (size_t)w * h * sizeof(uint32_t), ctx->stream));
+    }
+    return PT_OK;
+}
+
+int ensure_acc(pt_ctx *ctx, size_t pixels) {
+    if (pixels <= ctx->acc_capacity) return PT_OK;
+    for (int k = 0; k < 3; ++k) {
+        if (ctx->d_acc[k]) (void)hipFree(ctx->d_acc[k]);
+        ctx->d_acc[k] = nullptr;
+    }
+    ctx->acc_capacity = 0;
+    for (int k = 0; k < 3; ++k) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_acc[k], pixels * sizeof(double)));
+    ctx->acc_capacity = pixels;
+    return PT_OK;
+}
+
+D3 hd3(const double p[3]) { return D3{p[0], p[1], p[2]}; }
+D3 hsub(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+D3 hmul(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+D3 hcross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x}; }
+D3 hunit(D3 a) {
+    double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return D3{a.x / l, a.y / l, a.z / l};
+}
+
+// One wavefront pass over `pp.cpix * pp.s_count` paths.
+int run_pass(pt_ctx *ctx, const PassParams &pp) {
+    const uint32_t n = pp.cpix * pp.s_count;
+    const bool realtime = pp.mode == PT_MODE_REALTIME;
+    const bool profile = (ctx->flags & PT_CFG_PROFILE_STAGES) && (ctx->pass_counter % ctx->profile_period == 0);
+    const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
+    ctx->pass_counter++;
+    hipStream_t st = ctx->stream;
+    const uint32_t iters = pp.max_depth + 1;
+    size_t ev = 0;
+    if (profile) {
+        const size_t need = 2 * (2 + 2 * (size_t)iters);
+        while (ctx->events.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->events.push_back(e);
+        }
+    }
+    auto mark = [&]() -> hipError_t { return profile ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (iters + 1) * sizeof(uint32_t), st));
+    const int g_all = grid_for(ctx, n);
+    HIP_TRY(ctx, mark());
+    if (realtime)
+        hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->d_keys, ctx->d_l[0],
+                           ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
+    else
+        hipLaunchKernelGGL(k_raygen<false>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->d_keys, ctx->d_l[0],
+                           ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
+    HIP_TRY(ctx, mark());
+    for (uint32_t d = 0; d < iters; ++d) {
+        const Queue &qi = ctx->q[d & 1];
+        const Queue &qo = ctx->q[(d + 1) & 1];
+        HIP_TRY(ctx, mark());
+        if (count)
+            hipLaunchKernelGGL((k_extend<0, true>), dim3(g_all), dim3(kBlock), 0, st, qi, ctx->d_counts + d, ctx->view,
+                               0.001, kF64Max, ctx->d_keys, 0ull, d, ctx->d_hit_t, ctx->d_hit_id, ctx->d_trav);
+        else
+            hipLaunchKernelGGL((k_extend<0, false>), dim3(g_all), dim3(kBlock), 0, st, qi, ctx->d_counts + d, ctx->view,
+                               0.001, kF64Max, ctx->d_keys, 0ull, d, ctx->d_hit_t, ctx->d_hit_id, ctx->d_trav);
+        HIP_TRY(ctx, mark());
+        HIP_TRY(ctx, mark());
+        if (ctx->need_uv)
+            hipLaunchKernelGGL(k_shade<true>, dim3(g_all), dim3(kBlock), 0, st, qi, qo, ctx->d_counts + d,
+                               ctx->d_counts + d + 1, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
+                               ctx->d_l[1], ctx->d_l[2], d, pp.max_depth);
+        else
+            hipLaunchKernelGGL(k_shade<false>, dim3(g_all), dim3(kBlock), 0, st, qi, qo, ctx->d_counts + d,
+                               ctx->d_counts + d + 1, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
+                               ctx->d_l[1], ctx->d_l[2], d, pp.max_depth);
+        HIP_TRY(ctx, mark());
+    }
+    HIP_TRY(ctx, mark());
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, pp.cpix)), dim3(kBlock), 0, st, ctx->d_l[0], ctx->d_l[1],
+                       ctx->d_l[2], ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_image, ctx->d_frames, pp,
+                       ctx->d_counts, ctx->d_stats);
+    HIP_TRY(ctx, mark());
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->stats.paths += n;
+    ctx->stats.launches_raygen += 1;
+    ctx->stats.launches_extend += iters;
+    ctx->stats.launches_shade += iters;
+    ctx->stats.launches_resolve += 1;
+    if (profile) {
+        ctx->h_counts.resize(iters + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts.data(), ctx->d_counts, (iters + 1) * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        auto elapsed = [&](size_t a) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ctx->events[a], ctx->events[a + 1]);
+            return (double)ms;
+        };
+        size_t k = 0;
+        ctx->stats.ms_raygen += elapsed(k);
+        k += 2;
+        for (uint32_t d = 0; d < iters; ++d) {
+            ctx->stats.ms_extend += elapsed(k);
+            k += 2;
+            ctx->stats.ms_shade += elapsed(k);
+            k += 2;
+            ctx->stats.profiled_segments += ctx->h_counts[d];
+        }
+        ctx->stats.ms_resolve += elapsed(k);
+        ctx->stats.profiled_paths += n;
+        ctx->stats.profiled_passes += 1;
+        ctx->stats.profiled_bounce_launches += iters;
+    }
+    return PT_OK;
+}
+
+} // namespace
+
+// ================================================================================================================
+// extern "C"
+// ================================================================================================================
+extern "C" {
+
+int pt_create(const pt_config *cfg, pt_ctx **out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(pt_config)) return PT_ERR_INVALID_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return PT_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= n_dev) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = new (std::nothrow) pt_ctx();
+    if (!ctx) return PT_ERR_OUT_OF_MEMORY;
+    ctx->device = cfg->device;
+    ctx->seed = cfg->seed;
+    ctx->flags = cfg->flags;
+    ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
+    if (ctx->capacity < 1024) ctx->capacity = 1024;
+    if (const char *e = std::getenv("PTGPU_PROFILE_PERIOD")) {
+        long v = std::strtol(e, nullptr, 10);
+        if (v >= 1) ctx->profile_period = (uint32_t)v;
+    }
+    auto bail = [&](int code) {
+        pt_destroy(ctx);
+        return code;
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) return bail(PT_ERR_HIP);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(PT_ERR_HIP);
+    int rc = alloc_path_state(ctx);
+    if (rc != PT_OK) return bail(rc);
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
+                    ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
+                    ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2]};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pt_last_error(pt_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+void *pt_stream(pt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
+    if (!ctx || !scene) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    std::string err;
+    FlatScene flat;
+    int rc = flatten_scene(scene, flat, err);
+    if (rc != PT_OK) return set_error(ctx, rc, err);
+    if (flat.lights.empty()) return set_error(ctx, PT_ERR_INVALID_ARG, "scene has no light-shape list");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = false;
+    ctx->flat = std::move(flat);
+    const FlatScene &f = ctx->flat;
+    // transform / leaf tables are never empty on the device so kernels can index them unconditionally
+    std::vector<DevXform> xf = f.xforms;
+    if (xf.empty()) xf.push_back(DevXform{XF_FLIP, 0, 0, 0, 0});
+    if ((rc = upload(ctx, &ctx->d_ops, f.ops.data(), f.ops.size())) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_xforms, xf.data(), xf.size())) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_leaves, f.leaves.data(), f.leaves.size())) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_lights, f.lights.data(), f.lights.size())) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_materials, scene->materials, (size_t)scene->n_materials)) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_textures, scene->textures, (size_t)scene->n_textures)) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_texels, scene->texels, (size_t)scene->n_texel_bytes)) != PT_OK) return rc;
+    if ((rc = upload(ctx, &ctx->d_perlin, scene->perlin, scene->perlin ? (size_t)1 : (size_t)0)) != PT_OK) return rc;
+    SceneView &v = ctx->view;
+    v.ops = (const DevOp *)ctx->d_ops;
+    v.xforms = (const DevXform *)ctx->d_xforms;
+    v.leaves = (const DevLeaf *)ctx->d_leaves;
+    v.lights = (const DevLight *)ctx->d_lights;
+    v.materials = (const pt_material *)ctx->d_materials;
+    v.textures = (const pt_texture *)ctx->d_textures;
+    v.texels = (const uint8_t *)ctx->d_texels;
+    v.perlin = (const pt_perlin *)ctx->d_perlin;
+    v.n_traversal_ops = f.n_traversal_ops;
+    v.n_lights = (int32_t)f.lights.size();
+    v.has_medium = f.has_medium ? 1 : 0;
+    v.has_frames = f.has_frames ? 1 : 0;
+    ctx->need_uv = false;
+    for (int i = 0; i < scene->n_textures; ++i)
+        if (scene->textures[i].kind == PT_T_IMAGE) ctx->need_uv = true;
+    ctx->have_scene = true;
+    return PT_OK;
+}
+
+int pt_camera_set(pt_ctx *ctx, const pt_camera *c) {
+    if (!ctx || !c) return PT_ERR_INVALID_ARG;
+    // Camera::new, src/camera.rs:25-51
+    const double theta = c->vfov * kPi / 180.0;
+    const double half_height = std::tan(theta / 2.0);
+    const double half_width = c->aspect * half_height;
+    const D3 origin = hd3(c->origin);
+    const D3 w = hunit(hsub(origin, hd3(c->look_at)));
+    const D3 u = hunit(hcross(hd3(c->vup), w));
+    const D3 v = hcross(w, u);
+    CameraDev &cam = ctx->cam;
+    cam.origin = origin;
+    cam.lower_left_corner = hsub(hsub(hsub(origin, hmul(hmul(u, half_width), c->focus_dist)),
+                                      hmul(hmul(v, half_height), c->focus_dist)),
+                                 hmul(w, c->focus_dist));
+    cam.horizontal = hmul(hmul(hmul(u, 2.0), half_width), c->focus_dist);
+    cam.vertical = hmul(hmul(hmul(v, 2.0), half_height), c->focus_dist);
+    cam.u = u;
+    cam.v = v;
+    cam.time0 = c->time0;
+    cam.time1 = c->time1;
+    cam.lens_radius = c->aperture / 2.0;
+    ctx->have_camera = true;
+    return PT_OK;
+}
+
+int pt_image_bind(pt_ctx *ctx, void *device_rgba, uint32_t width, uint32_t height) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    ctx->d_frames = nullptr;
+    if (!device_rgba) {
+        ctx->image_external = false;
+        ctx->d_image = ctx->d_image_owned;
+        if (!ctx->d_image_owned) ctx->width = ctx->height = 0;
+        return PT_OK;
+    }
+    if (width == 0 || height == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "empty image");
+    if (ctx->d_image_owned) (void)hipFree(ctx->d_image_owned);
+    ctx->d_image_owned = nullptr;
+    ctx->image_external = true;
+    ctx->d_image = (float *)device_rgba;
+    ctx->width = width;
+    ctx->height = height;
+    return PT_OK;
+}
+
+void *pt_image_device_ptr(pt_ctx *ctx) { return ctx ? (void *)ctx->d_image : nullptr; }
+
+int pt_render(pt_ctx *ctx, const pt_render_args *a) {
+    if (!ctx || !a || a->struct_size != sizeof(pt_render_args)) return PT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_render before pt_scene_upload");
+    if (!ctx->have_camera) return set_error(ctx, PT_ERR_NO_CAMERA, "pt_render before pt_camera_set");
+    if (a->width == 0 || a->height == 0 || a->x0 >= a->x1 || a->y0 >= a->y1 || a->x1 > a->width || a->y1 > a->height)
+        return set_error(ctx, PT_ERR_INVALID_ARG, "bad tile rectangle");
+    if (a->spp == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "spp must be positive");
+    if (a->max_depth > (uint32_t)(kMaxDepthSlots - 2)) return set_error(ctx, PT_ERR_TOO_LARGE, "max_depth too large");
+    if (a->mode != PT_MODE_OFFLINE && a->mode != PT_MODE_REALTIME) return set_error(ctx, PT_ERR_INVALID_ARG, "bad mode");
+    if ((uint64_t)a->width * a->height > 0x7fffffffull) return set_error(ctx, PT_ERR_TOO_LARGE, "image too large");
+    (void)hipSetDevice(ctx->device);
+    int rc = ensure_image(ctx, a->width, a->height);
+    if (rc != PT_OK) return rc;
+
+    const uint32_t tw = a->x1 - a->x0, th = a->y1 - a->y0;
+    if (tw > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "tile row wider than the paths-in-flight budget");
+    // chunk = as many whole tile rows as fit the budget with at least one sample each
+    const uint32_t rows_per_chunk = std::max<uint32_t>(1, std::min<uint32_t>(th, ctx->capacity / tw));
+    rc = ensure_acc(ctx, (size_t)rows_per_chunk * tw);
+    if (rc != PT_OK) return rc;
+    for (uint32_t r0 = 0; r0 < th; r0 += rows_per_chunk) {
+        const uint32_t rows = std::min(rows_per_chunk, th - r0);
+        PassParams pp;
+        std::memset(&pp, 0, sizeof(pp));
+        pp.seed = ctx->seed;
+        pp.frame = a->frame;
+        pp.width = a->width;
+        pp.height = a->height;
+        pp.cx0 = a->x0;
+        pp.cy0 = a->y0 + r0;
+        pp.cw = tw;
+        pp.cpix = rows * tw;
+        pp.spp = a->spp;
+        pp.max_depth = a->max_depth;
+        pp.mode = a->mode;
+        const uint32_t s_per_pass = std::max<uint32_t>(1, std::min<uint32_t>(a->spp, ctx->capacity / pp.cpix));
+        for (uint32_t s0 = 0; s0 < a->spp; s0 += s_per_pass) {
+            pp.s_base = s0;
+            pp.s_count = std::min(s_per_pass, a->spp - s0);
+            pp.first_pass = s0 == 0;
+            pp.last_pass = s0 + pp.s_count >= a->spp;
+            rc = run_pass(ctx, pp);
+            if (rc != PT_OK) return rc;
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_accum_reset(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_image && ctx->width)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_image, 0, (size_t)ctx->width * ctx->height * 4 * sizeof(float), ctx->stream));
+    if (ctx->d_frames)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_frames, 0, (size_t)ctx->width * ctx->height * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats) {
+    if (!ctx || !rgba) return PT_ERR_INVALID_ARG;
+    if (!ctx->d_image) return set_error(ctx, PT_ERR_INVALID_ARG, "no image has been rendered");
+    if (n_floats != (size_t)ctx->width * ctx->height * 4) return set_error(ctx, PT_ERR_INVALID_ARG, "readback size mismatch");
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->d_image, n_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+static int intersect_common(pt_ctx *ctx, size_t n, double t_min, double t_max, uint64_t medium_seed, int repeats,
+                            double *mean_ms_out) {
+    const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
+    const uint32_t n32 = (uint32_t)n;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    const int g = grid_for(ctx, n);
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < repeats; ++r) {
+        if (count)
+            hipLaunchKernelGGL((k_extend<1, true>), dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], ctx->d_counts,
+                               ctx->view, t_min, t_max, ctx->d_keys, medium_seed, 0u, ctx->d_hit_t, ctx->d_hit_id,
+                               ctx->d_trav);
+        else
+            hipLaunchKernelGGL((k_extend<1, false>), dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], ctx->d_counts,
+                               ctx->view, t_min, t_max, ctx->d_keys, medium_seed, 0u, ctx->d_hit_t, ctx->d_hit_id,
+                               ctx->d_trav);
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (mean_ms_out) *mean_ms_out = (double)ms / (double)repeats;
+    ctx->stats.segments += 0;
+    return PT_OK;
+}
+
+int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double t_max, uint64_t medium_seed,
+                 pt_hit *out) {
+    if (!ctx || (n && (!rays || !out))) return PT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_intersect before pt_scene_upload");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    // batches larger than the queue capacity are processed in slices; the medium key uses the slice-local index
+    // offset by the slice start so results do not depend on the slicing
+    if (n > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "ray batch larger than the paths-in-flight budget");
+    void *d_rays = nullptr, *d_hits = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_rays, n * sizeof(pt_ray)));
+    if (hipMalloc(&d_hits, n * sizeof(pt_hit)) != hipSuccess) {
+        (void)hipFree(d_rays);
+        return set_error(ctx, PT_ERR_OUT_OF_MEMORY, "hipMalloc hits");
+    }
+    int rc = PT_OK;
+    do {
+        if (hipMemcpyAsync(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = set_error(ctx, PT_ERR_HIP, "H2D rays");
+            break;
+        }
+        const int g = grid_for(ctx, n);
+        hipLaunchKernelGGL(k_load_rays, dim3(g), dim3(kBlock), 0, ctx->stream, (const pt_ray *)d_rays, (uint32_t)n,
+                           ctx->q[0]);
+        rc = intersect_common(ctx, n, t_min, t_max, medium_seed, 1, nullptr);
+        if (rc != PT_OK) break;
+        hipLaunchKernelGGL(k_store_hits, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], (uint32_t)n, ctx->view,
+                           ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)d_hits);
+        if (hipMemcpyAsync(out, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            rc = set_error(ctx, PT_ERR_HIP, "D2H hits");
+            break;
+        }
+    } while (0);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    return rc;
+}
+
+int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double t_min, double t_max,
+                        uint64_t medium_seed, int repeats, double *mean_ms_out) {
+    if (!ctx || !d_rays_soa || n == 0 || repeats <= 0) return PT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_intersect_device before pt_scene_upload");
+    if (n > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "ray batch larger than the paths-in-flight budget");
+    (void)hipSetDevice(ctx->device);
+    Queue &q = ctx->q[0];
+    double *dst[7] = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, q.tm};
+    for (int k = 0; k < 7; ++k)
+        HIP_TRY(ctx, hipMemcpyAsync(dst[k], d_rays_soa + (size_t)k * n, n * sizeof(double), hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+    return intersect_common(ctx, n, t_min, t_max, medium_seed, repeats, mean_ms_out);
+}
+
+int pt_stats_get(pt_ctx *ctx, pt_stats *out) {
+    if (!ctx || !out) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    unsigned long long h[2] = {0, 0};
+    TraversalCounters tc{0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&tc, ctx->d_trav, sizeof(tc), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = ctx->stats;
+    out->segments = h[0];
+    out->nan_pixels = h[1];
+    out->node_visits = tc.node_visits;
+    out->prim_tests = tc.prim_tests;
+    return PT_OK;
+}
+
+int pt_stats_reset(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trav, 0, sizeof(TraversalCounters), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pass_counter = 0;
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,27 @@
+"""Test configuration: registers the `gpu` marker and exposes the product binding as the module `ptgpu`."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# The package directory has a hyphen in its name, so it is imported by string and aliased.
+ptgpu = importlib.import_module("path-tracer_amd")
+sys.modules.setdefault("ptgpu", ptgpu)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 20)
+    yield ctx
+    ctx.close()
