@@ -41,13 +41,16 @@ inline int op_axis(int32_t k) { return (k >> 8) & 0x3; }
 inline int op_chain_count(int32_t k) { return (k >> 16) & 0xff; }
 inline int32_t op_pack(int kind, int axis, int chain_count) { return kind | (axis << 8) | (chain_count << 16); }
 
-enum XformKind : int32_t { XF_TRANSLATE = 0, XF_ROTATE_Y = 1, XF_FLIP = 2 };
-struct DevXform { // 32 bytes
-    int32_t kind;
-    int32_t pad;
-    double a, b, c; // TRANSLATE: xyz ; ROTATE_Y: a = sin, b = cos
+// One transform step = Translate followed by RotateY followed by a normal flip, any of which may be the
+// identity (t = 0, sin = 0 / cos = 1, sign = +1). Applying an identity part is exact in f64 for finite
+// values (x - 0, 1 * x - 0 * z), so a wrapper chain keeps the reference's arithmetic while the device code
+// stays branch-free. The flattener merges a Translate directly followed by a RotateY into one step.
+struct DevXform { // 48 bytes
+    double tx, ty, tz; // Translate (src/hitable.rs:107-138)
+    double s, c;       // RotateY sin / cos (src/hitable.rs:140-216)
+    double sign;       // -1 when an odd number of FlipNormals (src/hitable.rs:80-105) sit at this step
 };
-static_assert(sizeof(DevXform) == 32, "DevXform must be 32 bytes");
+static_assert(sizeof(DevXform) == 48, "DevXform must be 48 bytes");
 
 struct DevLeaf { // 96 bytes: what finalising a hit needs beyond the op itself
     int32_t op;          // op holding the geometry parameters

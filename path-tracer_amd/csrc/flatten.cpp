@@ -8,6 +8,48 @@ namespace ptdev {
 
 namespace {
 
+// A wrapper as met in the graph; chains of these are compressed into DevXform steps when stored.
+enum SimpleKind { S_TRANSLATE, S_ROTATE_Y, S_FLIP };
+struct SimpleOp {
+    int kind;
+    double a, b, c;
+};
+
+DevXform identity_step() { return DevXform{0.0, 0.0, 0.0, 0.0, 1.0, 1.0}; }
+
+// [Translate][RotateY] in that order share a step; anything else starts a new one. Flips only negate the
+// final normal, so their parity rides on the last step (or on an identity step if the chain has no other).
+std::vector<DevXform> compress_chain(const std::vector<SimpleOp> &ops) {
+    std::vector<DevXform> out;
+    bool open = false, has_t = false, has_r = false;
+    double sign = 1.0;
+    DevXform cur = identity_step();
+    auto flush = [&]() {
+        if (open) out.push_back(cur);
+        cur = identity_step();
+        open = has_t = has_r = false;
+    };
+    for (const SimpleOp &o : ops) {
+        if (o.kind == S_FLIP) {
+            sign = -sign;
+        } else if (o.kind == S_TRANSLATE) {
+            if (has_t || has_r) flush();
+            cur.tx = o.a; cur.ty = o.b; cur.tz = o.c;
+            open = has_t = true;
+        } else {
+            if (has_r) flush();
+            cur.s = o.a; cur.c = o.b;
+            open = has_r = true;
+        }
+    }
+    flush();
+    if (sign < 0.0) {
+        if (out.empty()) out.push_back(identity_step());
+        out.back().sign = -1.0;
+    }
+    return out;
+}
+
 struct FrameRef {
     int32_t start = 0; // range of the frame's full chain in xforms[]
     int32_t count = 0;
@@ -45,7 +87,8 @@ class Flattener {
                     return fail(PT_ERR_INVALID_ARG, "image texture outside the texel blob");
             }
         }
-        std::vector<DevXform> local, full;
+        std::vector<SimpleOp> local;
+        std::vector<DevXform> full;
         int rc = emit(s_->root, local, full, FrameRef{}, 0, true, 0);
         if (rc != PT_OK) return rc;
         out_.n_traversal_ops = (int32_t)out_.ops.size();
@@ -86,7 +129,7 @@ class Flattener {
     }
 
     // Appends `full` ++ `local` to xforms[] and returns where it starts (0 if the chain is empty).
-    int32_t store_chain(const std::vector<DevXform> &full, const std::vector<DevXform> &local) {
+    int32_t store_chain(const std::vector<DevXform> &full, const std::vector<DevXform> &local) { // both compressed
         if (full.empty() && local.empty()) return 0;
         int32_t start = (int32_t)out_.xforms.size();
         out_.xforms.insert(out_.xforms.end(), full.begin(), full.end());
@@ -94,15 +137,7 @@ class Flattener {
         return start;
     }
 
-    static DevXform xf(int kind, double a, double b, double c) {
-        DevXform x;
-        x.kind = kind;
-        x.pad = 0;
-        x.a = a;
-        x.b = b;
-        x.c = c;
-        return x;
-    }
+    static SimpleOp xf(int kind, double a, double b, double c) { return SimpleOp{kind, a, b, c}; }
 
     // Fills geometry parameters of a primitive op from a graph node. Returns false if not a primitive.
     bool geometry_op(int h, DevOp &op, DevLeaf &leaf, int &rc) {
@@ -179,32 +214,33 @@ class Flattener {
         return PT_OK;
     }
 
-    int emit(int h, std::vector<DevXform> local, const std::vector<DevXform> &full, FrameRef frame, int frame_depth,
+    int emit(int h, std::vector<SimpleOp> local, const std::vector<DevXform> &full, FrameRef frame, int frame_depth,
              bool is_root, int guard) {
         if (!node_ok(h)) return fail(PT_ERR_INVALID_ARG, "hitable index out of range");
         if (guard > 4096) return fail(PT_ERR_INVALID_ARG, "hitable graph too deep or cyclic");
         const pt_hitable &n = s_->hitables[h];
         switch (n.kind) {
         case PT_H_FLIP:
-            local.push_back(xf(XF_FLIP, 0, 0, 0));
+            local.push_back(xf(S_FLIP, 0, 0, 0));
             return emit(n.child[0], local, full, frame, frame_depth, false, guard + 1);
         case PT_H_TRANSLATE:
-            local.push_back(xf(XF_TRANSLATE, n.f[0], n.f[1], n.f[2]));
+            local.push_back(xf(S_TRANSLATE, n.f[0], n.f[1], n.f[2]));
             return emit(n.child[0], local, full, frame, frame_depth, false, guard + 1);
         case PT_H_ROTATE_Y:
-            local.push_back(xf(XF_ROTATE_Y, n.f[0], n.f[1], 0.0));
+            local.push_back(xf(S_ROTATE_Y, n.f[0], n.f[1], 0.0));
             return emit(n.child[0], local, full, frame, frame_depth, false, guard + 1);
         case PT_H_BVH: {
             if (!local.empty()) {
                 // wrapped subtree: ENTER (apply the wrappers to the ray), the subtree, EXIT (restore)
-                if (local.size() > 255 || full.size() + local.size() > 255)
+                const std::vector<DevXform> steps = compress_chain(local);
+                if (full.size() + steps.size() > 255)
                     return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
-                int32_t start = store_chain(full, local);
+                int32_t start = store_chain(full, steps);
                 std::vector<DevXform> new_full(full);
-                new_full.insert(new_full.end(), local.begin(), local.end());
+                new_full.insert(new_full.end(), steps.begin(), steps.end());
                 DevOp enter;
                 std::memset(&enter, 0, sizeof(enter));
-                enter.kind = op_pack(OP_ENTER, 0, (int)local.size());
+                enter.kind = op_pack(OP_ENTER, 0, (int)steps.size());
                 enter.skip = -1;
                 enter.leaf = -1;
                 enter.chain_start = start + (int32_t)full.size();
@@ -212,7 +248,7 @@ class Flattener {
                 out_.has_frames = true;
                 if (frame_depth + 1 > out_.max_frame_depth) out_.max_frame_depth = frame_depth + 1;
                 FrameRef inner{start, (int32_t)new_full.size()};
-                int rc = emit(h, std::vector<DevXform>(), new_full, inner, frame_depth + 1, false, guard + 1);
+                int rc = emit(h, std::vector<SimpleOp>(), new_full, inner, frame_depth + 1, false, guard + 1);
                 if (rc != PT_OK) return rc;
                 DevOp exit_op;
                 std::memset(&exit_op, 0, sizeof(exit_op));
@@ -230,10 +266,10 @@ class Flattener {
             for (int k = 0; k < 6; ++k) box.d[k] = n.f[k];
             size_t at = out_.ops.size();
             out_.ops.push_back(box);
-            int rc = emit(n.child[0], std::vector<DevXform>(), full, frame, frame_depth, false, guard + 1);
+            int rc = emit(n.child[0], std::vector<SimpleOp>(), full, frame, frame_depth, false, guard + 1);
             if (rc != PT_OK) return rc;
             if (n.child[1] != n.child[0]) { // bvh.rs:47-49 duplicates a lone leaf; testing it once is equivalent
-                rc = emit(n.child[1], std::vector<DevXform>(), full, frame, frame_depth, false, guard + 1);
+                rc = emit(n.child[1], std::vector<SimpleOp>(), full, frame, frame_depth, false, guard + 1);
                 if (rc != PT_OK) return rc;
             }
             if (out_.ops.size() > (size_t)INT32_MAX) return fail(PT_ERR_TOO_LARGE, "too many ops");
@@ -246,7 +282,7 @@ class Flattener {
             if (n.list_start < 0 || n.list_count < 0 || n.list_start + n.list_count > s_->n_child_index)
                 return fail(PT_ERR_INVALID_ARG, "list range out of bounds");
             for (int k = 0; k < n.list_count; ++k) {
-                int rc = emit(s_->child_index[n.list_start + k], std::vector<DevXform>(), full, frame, frame_depth,
+                int rc = emit(s_->child_index[n.list_start + k], std::vector<SimpleOp>(), full, frame, frame_depth,
                               false, guard + 1);
                 if (rc != PT_OK) return rc;
             }
@@ -255,16 +291,17 @@ class Flattener {
         case PT_H_MEDIUM: {
             if (n.material < 0 || n.material >= s_->n_materials)
                 return fail(PT_ERR_INVALID_ARG, "medium phase function out of range");
-            if (full.size() + local.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+            const std::vector<DevXform> steps = compress_chain(local);
+            if (full.size() + steps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
             // boundary: wrappers down to one primitive
-            std::vector<DevXform> inner;
+            std::vector<SimpleOp> inner;
             int b = n.child[0];
             for (int g = 0;; ++g) {
                 if (!node_ok(b) || g > 255) return fail(PT_ERR_INVALID_ARG, "medium boundary out of range");
                 const pt_hitable &bn = s_->hitables[b];
-                if (bn.kind == PT_H_FLIP) inner.push_back(xf(XF_FLIP, 0, 0, 0));
-                else if (bn.kind == PT_H_TRANSLATE) inner.push_back(xf(XF_TRANSLATE, bn.f[0], bn.f[1], bn.f[2]));
-                else if (bn.kind == PT_H_ROTATE_Y) inner.push_back(xf(XF_ROTATE_Y, bn.f[0], bn.f[1], 0.0));
+                if (bn.kind == PT_H_FLIP) inner.push_back(xf(S_FLIP, 0, 0, 0));
+                else if (bn.kind == PT_H_TRANSLATE) inner.push_back(xf(S_TRANSLATE, bn.f[0], bn.f[1], bn.f[2]));
+                else if (bn.kind == PT_H_ROTATE_Y) inner.push_back(xf(S_ROTATE_Y, bn.f[0], bn.f[1], 0.0));
                 else break;
                 b = bn.child[0];
             }
@@ -274,29 +311,31 @@ class Flattener {
             if (!geometry_op(b, bop, bleaf, rc))
                 return fail(PT_ERR_UNSUPPORTED_SCENE, "medium boundary must be a (wrapped) sphere, rect or box");
             if (rc != PT_OK) return rc;
-            int32_t istart = store_chain(std::vector<DevXform>(), inner);
+            const std::vector<DevXform> isteps = compress_chain(inner);
+            if (isteps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+            int32_t istart = store_chain(std::vector<DevXform>(), isteps);
             bleaf.op = -1; // fixed below
             bleaf.full_start = istart;
-            bleaf.full_count = (int32_t)inner.size();
-            bop.kind = op_pack(bleaf.kind, bleaf.axis, (int)inner.size());
+            bleaf.full_count = (int32_t)isteps.size();
+            bop.kind = op_pack(bleaf.kind, bleaf.axis, (int)isteps.size());
             bop.chain_start = istart;
             bop.leaf = (int32_t)out_.leaves.size();
             out_.leaves.push_back(bleaf);
             int32_t bindex = (int32_t)boundary_ops_.size();
             boundary_ops_.push_back(bop);
 
-            int32_t start = store_chain(full, local);
+            int32_t start = store_chain(full, steps);
             DevLeaf leaf;
             std::memset(&leaf, 0, sizeof(leaf));
             leaf.kind = OP_MEDIUM;
             leaf.material = n.material;
             leaf.full_start = start;
-            leaf.full_count = (int32_t)(full.size() + local.size());
+            leaf.full_count = (int32_t)(full.size() + steps.size());
             for (int k = 0; k < 6; ++k) leaf.prim[k] = h;
             leaf.op = (int32_t)out_.ops.size();
             DevOp op;
             std::memset(&op, 0, sizeof(op));
-            op.kind = op_pack(OP_MEDIUM, 0, (int)local.size());
+            op.kind = op_pack(OP_MEDIUM, 0, (int)steps.size());
             op.d[0] = n.f[0];
             op.skip = bindex; // relocated once the traversal stream is complete
             op.leaf = (int32_t)out_.leaves.size();
@@ -312,13 +351,14 @@ class Flattener {
             int rc = PT_OK;
             if (!geometry_op(h, op, leaf, rc)) return fail(PT_ERR_INVALID_ARG, "unknown hitable kind");
             if (rc != PT_OK) return rc;
-            if (full.size() + local.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+            const std::vector<DevXform> steps = compress_chain(local);
+            if (full.size() + steps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
             if (out_.leaves.size() >= (size_t)(1 << 28)) return fail(PT_ERR_TOO_LARGE, "too many primitives");
-            int32_t start = store_chain(full, local);
+            int32_t start = store_chain(full, steps);
             leaf.full_start = start;
-            leaf.full_count = (int32_t)(full.size() + local.size());
+            leaf.full_count = (int32_t)(full.size() + steps.size());
             leaf.op = (int32_t)out_.ops.size();
-            op.kind = op_pack(leaf.kind, leaf.axis, (int)local.size());
+            op.kind = op_pack(leaf.kind, leaf.axis, (int)steps.size());
             op.chain_start = start + (int32_t)full.size();
             op.leaf = (int32_t)out_.leaves.size();
             out_.leaves.push_back(leaf);

@@ -95,30 +95,23 @@ struct SceneView {
 };
 
 // ------------------------------------------------------------ transforms --
-// Ray into a wrapper's child space: Translate::hit (src/hitable.rs:124) and RotateY::hit (204-206, via 182-187).
+// Ray into a wrapper's child space: Translate::hit (src/hitable.rs:124), then RotateY::hit (204-206, via 182-187).
 PT_DEV void xform_ray(const DevXform &x, D3 &o, D3 &d) {
-    if (x.kind == XF_TRANSLATE) {
-        o = o - d3(x.a, x.b, x.c);
-    } else if (x.kind == XF_ROTATE_Y) {
-        const double s = x.a, c = x.b;
-        o = d3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
-        d = d3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
-    }
+    o = o - d3(x.tx, x.ty, x.tz);
+    const double s = x.s, c = x.c;
+    o = d3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
+    d = d3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
 }
 PT_DEV void apply_chain(const DevXform *xf, int start, int count, D3 &o, D3 &d) {
     for (int k = 0; k < count; ++k) xform_ray(xf[start + k], o, d);
 }
-// Hit record back out of a wrapper: hitable.rs:95 (flip), 126 (translate), 209-210 (rotate, via 189-194).
+// Hit record back out of a wrapper: hitable.rs:209-210 (rotate, via 189-194), 126 (translate), 95 (flip).
 PT_DEV void unxform_hit(const DevXform &x, D3 &p, D3 &n) {
-    if (x.kind == XF_TRANSLATE) {
-        p = p + d3(x.a, x.b, x.c);
-    } else if (x.kind == XF_ROTATE_Y) {
-        const double s = x.a, c = x.b;
-        p = d3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
-        n = d3(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
-    } else {
-        n = -n;
-    }
+    const double s = x.s, c = x.c;
+    p = d3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+    n = d3(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
+    p = p + d3(x.tx, x.ty, x.tz);
+    n = n * x.sign;
 }
 
 // ------------------------------------------------------------ primitives --
@@ -347,7 +340,7 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double 
         r.u = (a - amin) / (amax - amin); // rect.rs:46-47,108-109
         r.v = (b - bmin) / (bmax - bmin);
         r.n = axis == 0 ? d3(1.0, 0.0, 0.0) : (axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
-        if (lf.kind == OP_BOXPRIM && (sub & 1)) r.n = -r.n; // faces 1, 3, 5 are wrapped in FlipNormals
+        if (lf.kind == OP_BOXPRIM) r.n = r.n * ((sub & 1) ? -1.0 : 1.0); // faces 1, 3, 5 are wrapped in FlipNormals
         break;
     }
     default: // OP_MEDIUM, volume.rs:51-59

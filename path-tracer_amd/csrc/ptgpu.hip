@@ -741,7 +741,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     const FlatScene &f = ctx->flat;
     // transform / leaf tables are never empty on the device so kernels can index them unconditionally
     std::vector<DevXform> xf = f.xforms;
-    if (xf.empty()) xf.push_back(DevXform{XF_FLIP, 0, 0, 0, 0});
+    if (xf.empty()) xf.push_back(DevXform{0.0, 0.0, 0.0, 0.0, 1.0, 1.0});
     if ((rc = upload(ctx, &ctx->d_ops, f.ops.data(), f.ops.size())) != PT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_xforms, xf.data(), xf.size())) != PT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_leaves, f.leaves.data(), f.leaves.size())) != PT_OK) return rc;
