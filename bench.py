@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s (pixels x spp / s) of the wavefront path tracer on the Cornell box,
+1024 x 1024 @ 1024 spp, max_depth 50 (the offline configuration of the reference: src/lib.rs:128-135),
+on N GPUs of one node.
+
+A step is one full render of the image. With N > 1 the image is cut into 64-row stripes dealt round-robin to the
+ranks (one process per GPU); every rank renders its stripes into its own copy of the f32 RGBA image and the
+stripes are gathered to rank 0 with one RCCL gather (torch.distributed, backend "nccl") inside the timed region.
+The scene and the RNG are keyed by global pixel and sample index, so the image does not depend on N.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+STRIPE_ROWS = 64
+SEED = 0x5EED0001
+
+
+def stripes_for(rank, world, height):
+    n_stripes = (height + STRIPE_ROWS - 1) // STRIPE_ROWS
+    return [(s * STRIPE_ROWS, min((s + 1) * STRIPE_ROWS, height)) for s in range(n_stripes) if s % world == rank]
+
+
+def algorithmic_bytes(V, P):
+    """Per-unit HBM bytes of the compact layout the roofline is priced on: a ray is 28 B (f32 origin, direction,
+    time), a hit 8 B, a BVH node / primitive / material record 32 B, a queue entry 48 B (ray + pixel + throughput).
+    extend: read ray, write hit, fetch V nodes + P primitives. shade: read queue entry + hit, fetch primitive +
+    material, write the next queue entry."""
+    b_ray = 28 + 8 + 32.0 * (V + P)
+    b_shade = 48 + 8 + 32 + 32 + 48
+    return b_ray, b_shade
+
+
+def cpu_baseline(scene, width, height, max_depth, target_seconds=12.0):
+    """Times the CPU oracle (f64 restatement of the reference, tile jobs on a thread pool) on a bounded sample
+    of the same workload: the same scene and image size at a reduced spp."""
+    import oracle_binding as ob
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    desc = scene.desc()
+    # calibrate on a 1-spp pass, then size the sample for ~target_seconds
+    _, st = ob.render(desc, scene.camera, width, height, 1, max_depth, seed=SEED, threads=threads)
+    rate = st.paths / max(st.seconds, 1e-9)
+    spp = int(max(1, min(64, round(target_seconds * rate / (width * height)))))
+    _, st = ob.render(desc, scene.camera, width, height, spp, max_depth, seed=SEED, threads=threads)
+    return {
+        "value": st.paths / st.seconds / 1e6,
+        "unit": "Mpaths/s",
+        "cores": int(st.threads),
+        "kind": "port",
+        "sample": f"cornell_box {width}x{height} @ {spp} spp, max_depth {max_depth}, {st.seconds:.1f} s "
+                  f"(f64 recursive oracle, {st.tiles} tile jobs)",
+        "S": st.segments / st.paths,
+        "V": st.node_visits / st.segments,
+        "P": st.prim_tests / st.segments,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--max-depth", type=int, default=50)
+    ap.add_argument("--scene", default="cornell_box")
+    ap.add_argument("--paths-in-flight", type=int, default=1 << 22)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pt = importlib.import_module("path-tracer_amd")
+    W, H = args.width, args.height
+    scene = pt.Scene.named(args.scene, W / H, seed=SEED)
+    ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight,
+                     flags=pt.PT_CFG_PROFILE_STAGES)
+    ctx.upload(scene)
+
+    # The image lives in a torch tensor so that RCCL can move it; the library renders straight into it.
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    ctx.bind_image(image.data_ptr(), W, H)
+    my_stripes = stripes_for(rank, world, H)
+    n_mine = len(my_stripes)
+    max_stripes = (len(stripes_for(0, world, H)))
+    pack = gather_list = None
+    if world > 1:
+        pack = torch.zeros((max_stripes, STRIPE_ROWS, W, 4), dtype=torch.float32, device=image.device)
+        if rank == 0:
+            gather_list = [torch.zeros_like(pack) for _ in range(world)]
+
+    def step(frame):
+        if world == 1:
+            ctx.render(W, H, args.spp, args.max_depth, frame=frame)
+            return
+        for (y0, y1) in my_stripes:
+            ctx.render(W, H, args.spp, args.max_depth, tile=(0, y0, W, y1), frame=frame)
+        for k, (y0, y1) in enumerate(my_stripes):
+            pack[k, : y1 - y0].copy_(image[y0:y1])
+        dist.gather(pack, gather_list, dst=0)
+        if rank == 0:
+            for r in range(1, world):
+                for k, (y0, y1) in enumerate(stripes_for(r, world, H)):
+                    image[y0:y1].copy_(gather_list[r][k, : y1 - y0])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    ctx.stats_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=image.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = ctx.stats()
+    paths_total = float(W) * H * args.spp * args.steps
+    value = paths_total / elapsed / 1e6
+    result = None
+    if rank == 0:
+        nan_frac = float(torch.isnan(image[..., :3]).any(dim=-1).float().mean().item())
+        cpu = None
+        V, P = 6.8, 8.8  # Cornell box counters from the oracle; replaced by the live ones below
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(scene, W, H, args.max_depth)
+            V, P = cpu["V"], cpu["P"]
+        b_ray, b_shade = algorithmic_bytes(V, P)
+        n_launch = max(int(st.profiled_bounce_launches), 1)
+        seg = float(st.profiled_segments)
+        ext_ms, shd_ms = st.ms_extend, st.ms_shade
+        dominant = "extend" if ext_ms >= shd_ms else "shade"
+        dom_ms = max(ext_ms, shd_ms)
+        dom_bytes_unit = b_ray if dominant == "extend" else b_shade
+        achieved = (seg * dom_bytes_unit) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(dominant)
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpaths/sec (pixels x spp / s), Cornell box offline render",
+            "value": value,
+            "unit": "Mpaths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} {W}x{H} @ {args.spp} spp, max_depth {args.max_depth}, "
+                            f"{'one tile' if world == 1 else f'{STRIPE_ROWS}-row stripes round-robin + RCCL gather'}",
+                "paths_in_flight": args.paths_in_flight,
+                "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
+                "nan_pixel_fraction": nan_frac,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"k_{dominant}",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": dom_ms / n_launch,
+                "algorithmic_bytes_per_launch": seg * dom_bytes_unit / n_launch,
+                "bytes_per_unit": dom_bytes_unit,
+                "units_per_launch": seg / n_launch,
+                "V": V,
+                "P": P,
+                "profiled_launches": n_launch,
+                "other": {
+                    "extend_ms_total": ext_ms,
+                    "shade_ms_total": shd_ms,
+                    "raygen_ms_total": st.ms_raygen,
+                    "resolve_ms_total": st.ms_resolve,
+                    "extend_Mrays_s": seg / (ext_ms * 1e-3) / 1e6 if ext_ms > 0 else None,
+                    "shade_Msegments_s": seg / (shd_ms * 1e-3) / 1e6 if shd_ms > 0 else None,
+                },
+            },
+        }
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+            result["config"]["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
