@@ -182,6 +182,9 @@ typedef struct pt_config {
 
 #define PT_CFG_PROFILE_STAGES 1u /* bracket every kernel launch of sampled passes with HIP events */
 #define PT_CFG_COUNT_TRAVERSAL 2u /* count node visits / primitive tests in the extend kernel */
+#define PT_CFG_EXACT 4u /* IEEE division everywhere and no fused multiply-add: bit-faithful to an f64 CPU evaluation
+                           of the reference's expressions; the default replaces quotients by refined reciprocals,
+                           fuses a*b+c and samples directions with f32 sin/cos (a few ulp per operation) */
 
 typedef enum pt_render_mode {
     PT_MODE_OFFLINE = 0,    /* overwrite rgb with the mean of spp samples (src/trace.rs:178-181) */

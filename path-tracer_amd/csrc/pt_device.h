@@ -73,9 +73,65 @@ PT_DEV double squared_length(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 PT_DEV double length(D3 a) { return sqrt(squared_length(a)); }
 PT_DEV D3 unit_vector(D3 a) { return a / length(a); }
 
-struct RayD {
-    D3 o, d;
-    double time;
+// ---------------------------------------------------------- math policy --
+// X = true  : "exact" mode. Every quotient is a true IEEE division and nothing is fused, so results match an
+//             f64 CPU evaluation of the reference's expressions bit for bit (up to libm differences).
+// X = false : "fast" mode (default). Quotients become a multiply by a Newton-refined v_rcp_f64 (about 1 ulp),
+//             sums of products use FMA, and the two trigonometric calls of the direction samplers run on the
+//             f32 transcendental unit. Geometry stays f64; results differ from exact mode by a few ulp per
+//             operation, far inside the 1e-4 relative bar on hit distances.
+PT_DEV double fast_rcp(double y) {
+    const double r0 = __builtin_amdgcn_rcp(y); // ~2^-26 relative error
+    double e = __builtin_fma(-y, r0, 1.0);
+    double r = __builtin_fma(e, r0, r0);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    // y = 0 or inf: the refinement produces NaN (0 * inf); keep the hardware's inf / 0, as IEEE division would
+    return (__builtin_isinf(r0) || r0 == 0.0) ? r0 : r;
+}
+template <bool X> struct M {
+    static PT_DEV double rcp(double y) {
+        if constexpr (X) return 1.0 / y;
+        else return fast_rcp(y);
+    }
+    static PT_DEV double div(double a, double b) {
+        if constexpr (X) return a / b;
+        else return a * fast_rcp(b);
+    }
+    static PT_DEV double mad(double a, double b, double c) { // a * b + c
+        if constexpr (X) return a * b + c;
+        else return __builtin_fma(a, b, c);
+    }
+    static PT_DEV double dot(D3 a, D3 b) {
+        if constexpr (X) return a.x * b.x + a.y * b.y + a.z * b.z;
+        else return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x));
+    }
+    static PT_DEV double squared_length(D3 a) { return dot(a, a); }
+    static PT_DEV double length(D3 a) { return sqrt(dot(a, a)); }
+    static PT_DEV D3 divs(D3 a, double s) {
+        if constexpr (X) return D3{a.x / s, a.y / s, a.z / s};
+        else {
+            const double r = fast_rcp(s);
+            return D3{a.x * r, a.y * r, a.z * r};
+        }
+    }
+    static PT_DEV D3 unit_vector(D3 a) { return divs(a, length(a)); }
+    static PT_DEV D3 point_at(D3 o, D3 d, double t) { // Ray::point_at_parameter, src/math/ray.rs:30-32
+        if constexpr (X) return D3{o.x + d.x * t, o.y + d.y * t, o.z + d.z * t};
+        else return D3{__builtin_fma(d.x, t, o.x), __builtin_fma(d.y, t, o.y), __builtin_fma(d.z, t, o.z)};
+    }
+    // cos(2 pi r), sin(2 pi r) for r in [0, 1)
+    static PT_DEV void sincos_2pi(double r, double &sn, double &cs) {
+        if constexpr (X) {
+            const double phi = 2.0 * kPi * r;
+            cs = cos(phi);
+            sn = sin(phi);
+        } else {
+            const float rf = (float)r; // v_sin_f32 / v_cos_f32 take their argument in revolutions
+            sn = (double)__builtin_amdgcn_sinf(rf);
+            cs = (double)__builtin_amdgcn_cosf(rf);
+        }
+    }
 };
 
 // ---------------------------------------------------------- scene tables --
@@ -96,20 +152,30 @@ struct SceneView {
 
 // ------------------------------------------------------------ transforms --
 // Ray into a wrapper's child space: Translate::hit (src/hitable.rs:124), then RotateY::hit (204-206, via 182-187).
-PT_DEV void xform_ray(const DevXform &x, D3 &o, D3 &d) {
+template <bool X> PT_DEV void xform_ray(const DevXform &x, D3 &o, D3 &d) {
     o = o - d3(x.tx, x.ty, x.tz);
     const double s = x.s, c = x.c;
-    o = d3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
-    d = d3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+    if constexpr (X) {
+        o = d3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
+        d = d3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+    } else {
+        o = d3(__builtin_fma(c, o.x, -(s * o.z)), o.y, __builtin_fma(s, o.x, c * o.z));
+        d = d3(__builtin_fma(c, d.x, -(s * d.z)), d.y, __builtin_fma(s, d.x, c * d.z));
+    }
 }
-PT_DEV void apply_chain(const DevXform *xf, int start, int count, D3 &o, D3 &d) {
-    for (int k = 0; k < count; ++k) xform_ray(xf[start + k], o, d);
+template <bool X> PT_DEV void apply_chain(const DevXform *xf, int start, int count, D3 &o, D3 &d) {
+    for (int k = 0; k < count; ++k) xform_ray<X>(xf[start + k], o, d);
 }
 // Hit record back out of a wrapper: hitable.rs:209-210 (rotate, via 189-194), 126 (translate), 95 (flip).
-PT_DEV void unxform_hit(const DevXform &x, D3 &p, D3 &n) {
+template <bool X> PT_DEV void unxform_hit(const DevXform &x, D3 &p, D3 &n) {
     const double s = x.s, c = x.c;
-    p = d3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
-    n = d3(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
+    if constexpr (X) {
+        p = d3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+        n = d3(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
+    } else {
+        p = d3(__builtin_fma(c, p.x, s * p.z), p.y, __builtin_fma(-s, p.x, c * p.z));
+        n = d3(__builtin_fma(c, n.x, s * n.z), n.y, __builtin_fma(-s, n.x, c * n.z));
+    }
     p = p + d3(x.tx, x.ty, x.tz);
     n = n * x.sign;
 }
@@ -143,49 +209,74 @@ PT_DEV bool aabb_hit(const double *b, D3 o, D3 inv, double tmin, double tmax) {
 }
 
 // Sphere::hit / MovingSphere::hit root selection (src/sphere.rs:44-81, 137-175). which = 0 near root, 1 far root.
+template <bool X>
 PT_DEV bool sphere_t(D3 center, double radius, D3 o, D3 d, double t_min, double t_max, double &t_out, int &which) {
     D3 oc = o - center;
-    double a = dot(d, d);
-    double b = dot(oc, d);
-    double c = dot(oc, oc) - radius * radius;
-    double discriminant = b * b - a * c;
+    double a = M<X>::dot(d, d);
+    double b = M<X>::dot(oc, d);
+    double c, discriminant;
+    if constexpr (X) {
+        c = M<X>::dot(oc, oc) - radius * radius;
+        discriminant = b * b - a * c;
+    } else {
+        c = __builtin_fma(-radius, radius, M<X>::dot(oc, oc));
+        discriminant = __builtin_fma(-a, c, b * b);
+    }
     if (discriminant > 0.0) {
-        double root = sqrt(b * b - a * c);
-        double temp = (-b - root) / a;
-        if (temp < t_max && temp > t_min) {
-            t_out = temp;
-            which = 0;
-            return true;
-        }
-        temp = (-b + root) / a;
-        if (temp < t_max && temp > t_min) {
-            t_out = temp;
-            which = 1;
-            return true;
+        double root = sqrt(discriminant);
+        if constexpr (X) {
+            double temp = (-b - root) / a;
+            if (temp < t_max && temp > t_min) {
+                t_out = temp;
+                which = 0;
+                return true;
+            }
+            temp = (-b + root) / a;
+            if (temp < t_max && temp > t_min) {
+                t_out = temp;
+                which = 1;
+                return true;
+            }
+        } else {
+            const double inv_a = fast_rcp(a);
+            double temp = (-b - root) * inv_a;
+            if (temp < t_max && temp > t_min) {
+                t_out = temp;
+                which = 0;
+                return true;
+            }
+            temp = (-b + root) * inv_a;
+            if (temp < t_max && temp > t_min) {
+                t_out = temp;
+                which = 1;
+                return true;
+            }
         }
     }
     return false;
 }
 
 // AxisAlignedRect::hit acceptance (src/rect.rs:97-105); axis 0 = X, 1 = Y, 2 = Z (63-85).
-PT_DEV bool rect_t(double amin, double amax, double bmin, double bmax, double c, int axis, D3 o, D3 d, double t_min,
-                   double t_max, double &t_out) {
+// `inv` = 1 / d per axis; only the fast mode uses it (exact mode divides, as the reference does).
+template <bool X>
+PT_DEV bool rect_t(double amin, double amax, double bmin, double bmax, double c, int axis, D3 o, D3 d, D3 inv,
+                   double t_min, double t_max, double &t_out) {
     double t, a, b;
     if (axis == 0) {
-        t = (c - o.x) / d.x;
+        t = X ? (c - o.x) / d.x : (c - o.x) * inv.x;
         if (t < t_min || t > t_max) return false;
-        a = o.y + t * d.y;
-        b = o.z + t * d.z;
+        a = M<X>::mad(t, d.y, o.y);
+        b = M<X>::mad(t, d.z, o.z);
     } else if (axis == 1) {
-        t = (c - o.y) / d.y;
+        t = X ? (c - o.y) / d.y : (c - o.y) * inv.y;
         if (t < t_min || t > t_max) return false;
-        a = o.x + t * d.x;
-        b = o.z + t * d.z;
+        a = M<X>::mad(t, d.x, o.x);
+        b = M<X>::mad(t, d.z, o.z);
     } else {
-        t = (c - o.z) / d.z;
+        t = X ? (c - o.z) / d.z : (c - o.z) * inv.z;
         if (t < t_min || t > t_max) return false;
-        a = o.x + t * d.x;
-        b = o.y + t * d.y;
+        a = M<X>::mad(t, d.x, o.x);
+        b = M<X>::mad(t, d.y, o.y);
     }
     if (a < amin || a > amax || b < bmin || b > bmax) return false;
     t_out = t;
@@ -207,7 +298,8 @@ PT_DEV void box_face(const double *pb, int k, double &amin, double &amax, double
     }
 }
 // AxisAlignedBox::hit = HitableList::hit over its six faces with a shrinking t_max (src/hitable.rs:51-62).
-PT_DEV bool box_t(const double *pb, D3 o, D3 d, double t_min, double t_max, double &t_out, int &face) {
+template <bool X>
+PT_DEV bool box_t(const double *pb, D3 o, D3 d, D3 inv, double t_min, double t_max, double &t_out, int &face) {
     double closest = t_max;
     bool any = false;
 #pragma unroll
@@ -215,7 +307,7 @@ PT_DEV bool box_t(const double *pb, D3 o, D3 d, double t_min, double t_max, doub
         double amin, amax, bmin, bmax, c, t;
         int axis;
         box_face(pb, k, amin, amax, bmin, bmax, c, axis);
-        if (rect_t(amin, amax, bmin, bmax, c, axis, o, d, t_min, closest, t)) {
+        if (rect_t<X>(amin, amax, bmin, bmax, c, axis, o, d, inv, t_min, closest, t)) {
             closest = t;
             face = k;
             any = true;
@@ -225,51 +317,61 @@ PT_DEV bool box_t(const double *pb, D3 o, D3 d, double t_min, double t_max, doub
     return any;
 }
 
-PT_DEV D3 moving_center(const double *pd, const double *e, double time) { // src/sphere.rs:130-132
-    return d3(pd[0], pd[1], pd[2]) + ((time - pd[4]) / pd[5]) * d3(e[0], e[1], e[2]);
+template <bool X> PT_DEV D3 moving_center(const double *pd, const double *e, double time) { // src/sphere.rs:130-132
+    return d3(pd[0], pd[1], pd[2]) + M<X>::div(time - pd[4], pd[5]) * d3(e[0], e[1], e[2]);
 }
 
 // One primitive op against a ray that is already in the op's frame; applies the op's own chain first.
+// `inv` is 1 / d of the frame ray (fast mode only; recomputed here if the op's chain rotates the ray).
 // `sub` is the near/far root for spheres and the face for boxes.
-PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, double time, double t_min, double t_max,
-                     double &t_out, int &sub) {
+template <bool X>
+PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, double time, double t_min,
+                     double t_max, double &t_out, int &sub) {
     const int kind = op.kind & 0xff;
     const int cc = (op.kind >> 16) & 0xff;
-    if (cc) apply_chain(sv.xforms, op.chain_start, cc, o, d);
+    if (cc) {
+        apply_chain<X>(sv.xforms, op.chain_start, cc, o, d);
+        if constexpr (!X) inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+    }
     sub = 0;
     switch (kind) {
     case OP_SPHERE:
-        return sphere_t(d3(op.d[0], op.d[1], op.d[2]), op.d[3], o, d, t_min, t_max, t_out, sub);
+        return sphere_t<X>(d3(op.d[0], op.d[1], op.d[2]), op.d[3], o, d, t_min, t_max, t_out, sub);
     case OP_MSPHERE:
-        return sphere_t(moving_center(op.d, sv.leaves[op.leaf].e, time), op.d[3], o, d, t_min, t_max, t_out, sub);
+        return sphere_t<X>(moving_center<X>(op.d, sv.leaves[op.leaf].e, time), op.d[3], o, d, t_min, t_max, t_out, sub);
     case OP_RECT:
-        return rect_t(op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], (op.kind >> 8) & 3, o, d, t_min, t_max, t_out);
+        return rect_t<X>(op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], (op.kind >> 8) & 3, o, d, inv, t_min, t_max,
+                         t_out);
     case OP_BOXPRIM:
-        return box_t(op.d, o, d, t_min, t_max, t_out, sub);
+        return box_t<X>(op.d, o, d, inv, t_min, t_max, t_out, sub);
     default:
         return false;
     }
 }
 
 // ConstantMedium::hit (src/volume.rs:24-65). The ray is in the medium's frame once the op's chain is applied.
-PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, double time, double t_min, double t_max,
-                       uint64_t pkey, uint32_t depth, double &t_out) {
+template <bool X>
+PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, double time, double t_min,
+                       double t_max, uint64_t pkey, uint32_t depth, double &t_out) {
     const int cc = (op.kind >> 16) & 0xff;
-    if (cc) apply_chain(sv.xforms, op.chain_start, cc, o, d);
+    if (cc) {
+        apply_chain<X>(sv.xforms, op.chain_start, cc, o, d);
+        if constexpr (!X) inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+    }
     const DevOp &bop = sv.ops[op.skip];
     double t1, t2;
     int sub;
-    if (!prim_hit(sv, bop, o, d, time, -kF64Max, kF64Max, t1, sub)) return false;
-    if (!prim_hit(sv, bop, o, d, time, t1 + 0.0001, kF64Max, t2, sub)) return false;
+    if (!prim_hit<X>(sv, bop, o, d, inv, time, -kF64Max, kF64Max, t1, sub)) return false;
+    if (!prim_hit<X>(sv, bop, o, d, inv, time, t1 + 0.0001, kF64Max, t2, sub)) return false;
     t1 = fmax(t1, t_min);
     t2 = fmin(t2, t_max);
     if (t1 >= t2) return false;
-    double ray_length = length(d);
+    double ray_length = M<X>::length(d);
     double distance_inside_boundary = (t2 - t1) * ray_length;
     double xi = medium_draw(pkey, depth, sv.leaves[op.leaf].prim[0]);
-    double hit_distance = -(1.0 / op.d[0]) * log(xi);
+    double hit_distance = -M<X>::rcp(op.d[0]) * log(xi);
     if (hit_distance < distance_inside_boundary) {
-        t_out = t1 + hit_distance / ray_length;
+        t_out = t1 + M<X>::div(hit_distance, ray_length);
         return true;
     }
     return false;
@@ -293,10 +395,10 @@ PT_DEV void get_sphere_uv(D3 p, double &u, double &v) { // src/sphere.rs:8-14
 // Rebuilds the HitRecord of the closest hit from (world ray, t, leaf, sub): the leaf's full chain takes the
 // ray to the primitive's space with the same sequence of operations the traversal used, the record is built
 // there as the primitive's hit() does, then carried back out through the wrappers in reverse.
-template <bool NEED_UV>
+template <bool X, bool NEED_UV>
 PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double t, int leaf_id, int sub) {
     const DevLeaf lf = sv.leaves[leaf_id];
-    apply_chain(sv.xforms, lf.full_start, lf.full_count, o, d);
+    apply_chain<X>(sv.xforms, lf.full_start, lf.full_count, o, d);
     HitRec r;
     r.t = t;
     r.u = 0.0;
@@ -304,26 +406,20 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double 
     r.mat = lf.material;
     r.prim = lf.prim[0];
     const DevOp &op = sv.ops[lf.op];
-    D3 point = o + (d * t); // Ray::point_at_parameter, src/math/ray.rs:30-32
+    D3 point = M<X>::point_at(o, d, t);
     r.p = point;
-    switch (lf.kind) {
-    case OP_SPHERE: {
+    if (lf.kind == OP_SPHERE) {
         D3 c = d3(op.d[0], op.d[1], op.d[2]);
         if (NEED_UV) {
-            if (sub == 0) get_sphere_uv((c - point) / op.d[3], r.u, r.v); // sphere.rs:56
-            else get_sphere_uv(c - point, r.u, r.v);                      // sphere.rs:69
+            if (sub == 0) get_sphere_uv(M<X>::divs(c - point, op.d[3]), r.u, r.v); // sphere.rs:56
+            else get_sphere_uv(c - point, r.u, r.v);                               // sphere.rs:69
         }
-        r.n = (point - c) / op.d[3];
-        break;
-    }
-    case OP_MSPHERE: {
-        D3 c = moving_center(op.d, lf.e, time);
+        r.n = M<X>::divs(point - c, op.d[3]);
+    } else if (lf.kind == OP_MSPHERE) {
+        D3 c = moving_center<X>(op.d, lf.e, time);
         if (NEED_UV) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
-        r.n = (point - c) / op.d[3];
-        break;
-    }
-    case OP_RECT:
-    case OP_BOXPRIM: {
+        r.n = M<X>::divs(point - c, op.d[3]);
+    } else if (lf.kind == OP_RECT || lf.kind == OP_BOXPRIM) {
         double amin, amax, bmin, bmax, c;
         int axis;
         if (lf.kind == OP_RECT) {
@@ -333,21 +429,20 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double 
             box_face(op.d, sub, amin, amax, bmin, bmax, c, axis);
             r.prim = lf.prim[sub];
         }
-        double a, b;
-        if (axis == 0) { a = o.y + t * d.y; b = o.z + t * d.z; }
-        else if (axis == 1) { a = o.x + t * d.x; b = o.z + t * d.z; }
-        else { a = o.x + t * d.x; b = o.y + t * d.y; }
-        r.u = (a - amin) / (amax - amin); // rect.rs:46-47,108-109
-        r.v = (b - bmin) / (bmax - bmin);
+        if (NEED_UV) {
+            double a, b;
+            if (axis == 0) { a = M<X>::mad(t, d.y, o.y); b = M<X>::mad(t, d.z, o.z); }
+            else if (axis == 1) { a = M<X>::mad(t, d.x, o.x); b = M<X>::mad(t, d.z, o.z); }
+            else { a = M<X>::mad(t, d.x, o.x); b = M<X>::mad(t, d.y, o.y); }
+            r.u = M<X>::div(a - amin, amax - amin); // rect.rs:46-47,108-109
+            r.v = M<X>::div(b - bmin, bmax - bmin);
+        }
         r.n = axis == 0 ? d3(1.0, 0.0, 0.0) : (axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
         if (lf.kind == OP_BOXPRIM) r.n = r.n * ((sub & 1) ? -1.0 : 1.0); // faces 1, 3, 5 are wrapped in FlipNormals
-        break;
-    }
-    default: // OP_MEDIUM, volume.rs:51-59
+    } else { // OP_MEDIUM, volume.rs:51-59
         r.n = d3(1.0, 0.0, 0.0);
-        break;
     }
-    for (int k = lf.full_count - 1; k >= 0; --k) unxform_hit(sv.xforms[lf.full_start + k], r.p, r.n);
+    for (int k = lf.full_count - 1; k >= 0; --k) unxform_hit<X>(sv.xforms[lf.full_start + k], r.p, r.n);
     return r;
 }
 
@@ -419,28 +514,31 @@ PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) 
     }
     return d3(0.0, 0.0, 0.0);
 }
+// True when a texture's value depends on the surface (u, v) of the hit.
+PT_DEV bool texture_is_constant(const SceneView &sv, int tex) { return sv.textures[tex].kind == PT_T_CONSTANT; }
 
 // -------------------------------------------------------------- samplers --
 struct Onb { // src/onb.rs:18-37
     D3 u, v, w;
 };
-PT_DEV Onb onb_from_w(D3 n) {
-    D3 w = unit_vector(n);
+template <bool X> PT_DEV Onb onb_from_w(D3 n) {
+    D3 w = M<X>::unit_vector(n);
     D3 a = fabs(w.x) > 0.9 ? d3(0.0, 1.0, 0.0) : d3(1.0, 0.0, 0.0);
-    D3 v = unit_vector(cross(w, a));
+    D3 v = M<X>::unit_vector(cross(w, a));
     D3 u = cross(w, v);
     return Onb{u, v, w};
 }
 PT_DEV D3 onb_local(const Onb &b, D3 a) { return b.u * a.x + b.v * a.y + b.w * a.z; }
 
-PT_DEV D3 random_cosine_direction(Rng &g) { // src/material.rs:10-19
+template <bool X> PT_DEV D3 random_cosine_direction(Rng &g) { // src/material.rs:10-19
     double r1 = g.next();
     double r2 = g.next();
     double z = sqrt(1.0 - r2);
-    double phi = 2.0 * kPi * r1;
+    double sn, cs;
+    M<X>::sincos_2pi(r1, sn, cs);
     double r2_sqrt = sqrt(r2);
-    double x = cos(phi) * r2_sqrt;
-    double y = sin(phi) * r2_sqrt;
+    double x = cs * r2_sqrt;
+    double y = sn * r2_sqrt;
     return d3(x, y, z);
 }
 PT_DEV D3 random_in_unit_sphere(Rng &g) { // src/material.rs:21-31
@@ -465,52 +563,59 @@ PT_DEV D3 random_in_unit_disk(Rng &g) { // src/camera.rs:221-228
     }
     return nv;
 }
-PT_DEV D3 random_to_sphere(Rng &g, double radius, double distance_squared) { // src/sphere.rs:16-25
+template <bool X> PT_DEV D3 random_to_sphere(Rng &g, double radius, double distance_squared) { // src/sphere.rs:16-25
     double r1 = g.next();
     double r2 = g.next();
-    double z = 1.0 + r2 * (sqrt(1.0 - radius * radius / distance_squared) - 1.0);
-    double phi = 2.0 * kPi * r1;
+    double z = 1.0 + r2 * (sqrt(1.0 - M<X>::div(radius * radius, distance_squared)) - 1.0);
+    double sn, cs;
+    M<X>::sincos_2pi(r1, sn, cs);
     double c = sqrt(1.0 - z * z);
-    double x = cos(phi) * c;
-    double y = sin(phi) * c;
+    double x = cs * c;
+    double y = sn * c;
     return d3(x, y, z);
 }
 
 // ---------------------------------------------------------------- lights --
 // Hitable::pdf_value of one light shape (src/sphere.rs:87-95, src/rect.rs:124-133, default src/hitable.rs:30-32).
-PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3 direction) {
+template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3 direction) {
     if (l.kind == LIGHT_SPHERE) {
         double t;
         int which;
         D3 c = d3(l.d[0], l.d[1], l.d[2]);
-        if (sphere_t(c, l.d[3], origin, direction, 0.001, kF64Max, t, which)) {
-            double cos_theta_max = sqrt(1.0 - l.d[3] * l.d[3] / squared_length(c - origin));
+        if (sphere_t<X>(c, l.d[3], origin, direction, 0.001, kF64Max, t, which)) {
+            double cos_theta_max = sqrt(1.0 - M<X>::div(l.d[3] * l.d[3], M<X>::squared_length(c - origin)));
             double solid_angle = 2.0 * kPi * (1.0 - cos_theta_max);
-            return 1.0 / solid_angle;
+            return M<X>::rcp(solid_angle);
         }
         return 0.0;
     }
     if (l.kind == LIGHT_RECT) {
         double t;
-        if (rect_t(l.d[0], l.d[1], l.d[2], l.d[3], l.d[4], l.axis, origin, direction, 0.001, kF64Max, t)) {
+        D3 inv = d3(0.0, 0.0, 0.0);
+        if constexpr (!X) {
+            const double dk = l.axis == 0 ? direction.x : (l.axis == 1 ? direction.y : direction.z);
+            const double r = fast_rcp(dk);
+            inv = d3(r, r, r);
+        }
+        if (rect_t<X>(l.d[0], l.d[1], l.d[2], l.d[3], l.d[4], l.axis, origin, direction, inv, 0.001, kF64Max, t)) {
             double area = (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]);
-            double v_sq_length = squared_length(direction);
+            double v_sq_length = M<X>::squared_length(direction);
             double distance_sq = t * t * v_sq_length;
             D3 normal = l.axis == 0 ? d3(1.0, 0.0, 0.0) : (l.axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
-            double cosine = fabs(dot(direction, normal) / sqrt(v_sq_length));
-            return distance_sq / (cosine * area);
+            double cosine = fabs(M<X>::div(dot(direction, normal), sqrt(v_sq_length)));
+            return M<X>::div(distance_sq, cosine * area);
         }
         return 0.0;
     }
     return 0.0;
 }
 // Hitable::random of one light shape (src/sphere.rs:96-101, src/rect.rs:135-144, default src/hitable.rs:33-35).
-PT_DEV D3 light_random(const DevLight &l, Rng &g, D3 origin) {
+template <bool X> PT_DEV D3 light_random(const DevLight &l, Rng &g, D3 origin) {
     if (l.kind == LIGHT_SPHERE) {
         D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
-        double distance_sq = squared_length(direction);
-        Onb uvw = onb_from_w(direction);
-        return onb_local(uvw, random_to_sphere(g, l.d[3], distance_sq));
+        double distance_sq = M<X>::squared_length(direction);
+        Onb uvw = onb_from_w<X>(direction);
+        return onb_local(uvw, random_to_sphere<X>(g, l.d[3], distance_sq));
     }
     if (l.kind == LIGHT_RECT) {
         double random_a = l.d[0] + g.next() * (l.d[1] - l.d[0]);
@@ -522,23 +627,23 @@ PT_DEV D3 light_random(const DevLight &l, Rng &g, D3 origin) {
     return d3(1.0, 0.0, 0.0);
 }
 // HitableList::pdf_value / random over the light list (src/hitable.rs:66-77).
-PT_DEV double lights_pdf_value(const SceneView &sv, D3 origin, D3 direction) {
+template <bool X> PT_DEV double lights_pdf_value(const SceneView &sv, D3 origin, D3 direction) {
     double weight = 1.0 / (double)sv.n_lights;
     double sum = 0.0;
-    for (int k = 0; k < sv.n_lights; ++k) sum += weight * light_pdf_value(sv.lights[k], origin, direction);
+    for (int k = 0; k < sv.n_lights; ++k) sum += weight * light_pdf_value<X>(sv.lights[k], origin, direction);
     return sum;
 }
-PT_DEV D3 lights_random(const SceneView &sv, Rng &g, D3 origin) {
+template <bool X> PT_DEV D3 lights_random(const SceneView &sv, Rng &g, D3 origin) {
     double x = (double)sv.n_lights * g.next();
     int index = (int)x;
-    return light_random(sv.lights[index], g, origin);
+    return light_random<X>(sv.lights[index], g, origin);
 }
 
 // ------------------------------------------------------------- materials --
-PT_DEV D3 reflect(D3 v, D3 n) { return v - (2.0 * dot(v, n) * n); } // src/material.rs:50-52
-PT_DEV bool refract(D3 v, D3 n, double ni_over_nt, D3 &refracted) { // src/material.rs:54-64
-    D3 uv = unit_vector(v);
-    double dt = dot(uv, n);
+template <bool X> PT_DEV D3 reflect(D3 v, D3 n) { return v - (2.0 * M<X>::dot(v, n) * n); } // src/material.rs:50-52
+template <bool X> PT_DEV bool refract(D3 v, D3 n, double ni_over_nt, D3 &refracted) { // src/material.rs:54-64
+    D3 uv = M<X>::unit_vector(v);
+    double dt = M<X>::dot(uv, n);
     double discriminant = 1.0 - ni_over_nt * ni_over_nt * (1.0 - dt * dt);
     if (discriminant > 0.0) {
         refracted = ni_over_nt * (uv - n * dt) - n * sqrt(discriminant);
@@ -546,10 +651,14 @@ PT_DEV bool refract(D3 v, D3 n, double ni_over_nt, D3 &refracted) { // src/mater
     }
     return false;
 }
-PT_DEV double schlick(double cosine, double ref_idx) { // src/material.rs:66-70
-    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+template <bool X> PT_DEV double schlick(double cosine, double ref_idx) { // src/material.rs:66-70
+    double r0 = M<X>::div(1.0 - ref_idx, 1.0 + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0 - r0) * pow(1.0 - cosine, 5.0);
+    if constexpr (X) return r0 + (1.0 - r0) * pow(1.0 - cosine, 5.0);
+    else {
+        const double m = 1.0 - cosine, m2 = m * m;
+        return r0 + (1.0 - r0) * (m2 * m2 * m);
+    }
 }
 
 // Material::emitted (src/material.rs:145-147 default, 303-305 Lambertian, 325-331 DiffuseLight).

@@ -145,26 +145,37 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, uint64_t *keys, doub
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// extend: threaded, stackless traversal of the op stream, one ray per lane
+// extend: stackless traversal of the threaded op stream
 // ------------------------------------------------------------------------------------------------------------
-// KEYMODE 0: the path's key is keys[pid[i]] (render); 1: intersect_key(medium_seed, i) (pt_intersect)
-template <int KEYMODE, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(Queue q, const uint32_t *count_ptr, SceneView sv, double t_min,
-                                                   double t_max_in, const uint64_t *keys, uint64_t medium_seed,
-                                                   uint32_t depth, double *hit_t, int32_t *hit_id,
-                                                   TraversalCounters *counters) {
-    const uint32_t n = *count_ptr;
+struct ExtendArgs {
+    const uint32_t *count_ptr;
+    double t_min, t_max;
+    const uint64_t *keys;  // key_mode 0: the path's key is keys[pid[i]] (render)
+    uint64_t medium_seed;  // key_mode 1: intersect_key(medium_seed, i) (pt_intersect)
+    uint32_t key_mode;
+    uint32_t depth;
+    double *hit_t;
+    int32_t *hit_id;
+    TraversalCounters *counters; // nullptr unless PT_CFG_COUNT_TRAVERSAL
+};
+
+// Per-lane form: every lane walks the stream on its own index. Used when the stream is long (thousands of ops)
+// and lanes of a wave visit mostly different nodes.
+template <bool X>
+__global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, ExtendArgs a) {
+    const uint32_t n = *a.count_ptr;
+    const bool count = a.counters != nullptr;
     unsigned long long my_nodes = 0, my_prims = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const D3 wo = d3(q.ox[i], q.oy[i], q.oz[i]);
         const D3 wd = d3(q.dx[i], q.dy[i], q.dz[i]);
         const double time = q.tm[i];
         uint64_t pkey = 0;
-        if (sv.has_medium) pkey = (KEYMODE == 0) ? keys[q.pid[i]] : intersect_key(medium_seed, i);
+        if (sv.has_medium) pkey = (a.key_mode == 0) ? a.keys[q.pid[i]] : intersect_key(a.medium_seed, i);
 
         D3 o = wo, d = wd;
-        D3 inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        double closest = t_max_in;
+        D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+        double closest = a.t_max;
         int32_t best = -1;
         int32_t cur = 0;
         const int32_t end = sv.n_traversal_ops;
@@ -173,43 +184,148 @@ __global__ __launch_bounds__(kBlock) void k_extend(Queue q, const uint32_t *coun
             const int32_t kword = op->kind;
             const int kind = kword & 0xff;
             if (kind == OP_BOX) {
-                if (COUNT) ++my_nodes;
-                if (aabb_hit(op->d, o, inv, t_min, closest)) cur += 1;
+                if (count) ++my_nodes;
+                if (aabb_hit(op->d, o, inv, a.t_min, closest)) cur += 1;
                 else cur = op->skip;
                 continue;
             }
             if (kind == OP_ENTER) {
-                apply_chain(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
-                inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                apply_chain<X>(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
+                inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
             } else if (kind == OP_EXIT) {
                 o = wo;
                 d = wd;
-                apply_chain(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
-                inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                apply_chain<X>(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
+                inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
             } else if (kind == OP_MEDIUM) {
-                if (COUNT) my_prims += 2;
+                if (count) my_prims += 2;
                 double t;
-                if (medium_hit(sv, *op, o, d, time, t_min, closest, pkey, depth, t)) {
+                if (medium_hit<X>(sv, *op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t)) {
                     closest = t;
                     best = op->leaf;
                 }
             } else {
-                if (COUNT) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
+                if (count) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
                 double t;
                 int sub;
-                if (prim_hit(sv, *op, o, d, time, t_min, closest, t, sub)) {
+                if (prim_hit<X>(sv, *op, o, d, inv, time, a.t_min, closest, t, sub)) {
                     closest = t;
                     best = op->leaf | (sub << 28);
                 }
             }
             cur += 1;
         }
-        hit_t[i] = closest;
-        hit_id[i] = best;
+        a.hit_t[i] = closest;
+        a.hit_id[i] = best;
     }
-    if (COUNT) {
-        atomicAdd(&counters->node_visits, my_nodes);
-        atomicAdd(&counters->prim_tests, my_prims);
+    if (count) {
+        atomicAdd(&a.counters->node_visits, my_nodes);
+        atomicAdd(&a.counters->prim_tests, my_prims);
+    }
+}
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int32_t o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Wave-uniform form for short streams (a Cornell box is 15 ops): the wave steps through the stream together.
+// Each lane keeps its own "next op" index; the wave executes op c for the lanes whose index is c, where c is the
+// smallest index any lane still wants. The op record is therefore fetched once per wave through the scalar cache
+// (s_load) into SGPRs instead of once per lane through the vector memory path, all lanes of a wave run the same
+// primitive test, and per-lane order (hence every result) is exactly that of the per-lane form.
+typedef const DevOp __attribute__((address_space(4))) *ConstOpPtr;
+
+__device__ __forceinline__ DevOp load_op_uniform(const DevOp *p) {
+    ConstOpPtr cp = (ConstOpPtr)p;
+    DevOp op;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) op.d[k] = cp->d[k];
+    op.kind = cp->kind;
+    op.skip = cp->skip;
+    op.leaf = cp->leaf;
+    op.chain_start = cp->chain_start;
+    return op;
+}
+
+template <bool X>
+__global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, ExtendArgs a) {
+    const uint32_t n = *a.count_ptr;
+    const bool count = a.counters != nullptr;
+    unsigned long long my_nodes = 0, my_prims = 0;
+    const int32_t end = sv.n_traversal_ops;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t il = valid ? i : 0u;
+        const D3 wo = d3(q.ox[il], q.oy[il], q.oz[il]);
+        const D3 wd = d3(q.dx[il], q.dy[il], q.dz[il]);
+        const double time = q.tm[il];
+        uint64_t pkey = 0;
+        if (sv.has_medium) pkey = (a.key_mode == 0) ? a.keys[q.pid[il]] : intersect_key(a.medium_seed, il);
+
+        D3 o = wo, d = wd;
+        D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+        double closest = a.t_max;
+        int32_t best = -1;
+        int32_t cur = valid ? 0 : 0x7fffffff;
+        int32_t c = -1;
+        for (;;) {
+            c += 1;
+            if (__ballot(cur == c) == 0ull) c = wave_min_i32(cur); // nobody wants the next op: jump ahead
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= end) break;
+            const DevOp op = load_op_uniform(sv.ops + c); // uniform address: scalar loads
+            const int32_t kword = op.kind;
+            const int kind = kword & 0xff;
+            const bool mine = cur == c;
+            if (kind == OP_BOX) {
+                if (mine) {
+                    if (count) ++my_nodes;
+                    cur = aabb_hit(op.d, o, inv, a.t_min, closest) ? c + 1 : op.skip;
+                }
+                continue;
+            }
+            if (mine) {
+                if (kind == OP_ENTER) {
+                    apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, o, d);
+                    inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+                } else if (kind == OP_EXIT) {
+                    o = wo;
+                    d = wd;
+                    apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, o, d);
+                    inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+                } else if (kind == OP_MEDIUM) {
+                    if (count) my_prims += 2;
+                    double t;
+                    if (medium_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t)) {
+                        closest = t;
+                        best = op.leaf;
+                    }
+                } else {
+                    if (count) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
+                    double t;
+                    int sub;
+                    if (prim_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, t, sub)) {
+                        closest = t;
+                        best = op.leaf | (sub << 28);
+                    }
+                }
+                cur = c + 1;
+            }
+        }
+        if (valid) {
+            a.hit_t[i] = closest;
+            a.hit_id[i] = best;
+        }
+    }
+    if (count) {
+        atomicAdd(&a.counters->node_visits, my_nodes);
+        atomicAdd(&a.counters->prim_tests, my_prims);
     }
 }
 
@@ -226,7 +342,7 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
     }
 }
 
-template <bool NEED_UV>
+template <bool X, bool NEED_UV>
 __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint32_t *n_in, uint32_t *n_out,
                                                   SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   const uint64_t *keys, double *lx, double *ly, double *lz,
@@ -251,33 +367,34 @@ __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
                 Rng g{keys[pid], qi.rn[i]};
-                const HitRec rec = finalize_hit<NEED_UV>(sv, o, d, time, hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
+                const HitRec rec = finalize_hit<X, NEED_UV>(sv, o, d, time, hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
                 const pt_material m = sv.materials[rec.mat];
                 const D3 emissive = emitted(sv, m, d, rec);
                 bool done = true;
                 if (depth < max_depth) {
                     if (m.kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
                         D3 outward_normal;
-                        D3 reflected = reflect(d, rec.n);
+                        D3 reflected = reflect<X>(d, rec.n);
                         double ni_over_nt, reflect_prob, cosine;
                         D3 refracted = d3(0.0, 0.0, 0.0);
-                        if (dot(d, rec.n) > 0.0) {
+                        const double d_dot_n = M<X>::dot(d, rec.n);
+                        if (d_dot_n > 0.0) {
                             outward_normal = -rec.n;
                             ni_over_nt = m.ref_idx;
-                            cosine = m.ref_idx * dot(d, rec.n) / length(d);
+                            cosine = M<X>::div(m.ref_idx * d_dot_n, M<X>::length(d));
                         } else {
                             outward_normal = rec.n;
-                            ni_over_nt = 1.0 / m.ref_idx;
-                            cosine = -dot(d, rec.n) / length(d);
+                            ni_over_nt = M<X>::rcp(m.ref_idx);
+                            cosine = M<X>::div(-d_dot_n, M<X>::length(d));
                         }
-                        if (refract(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick(cosine, m.ref_idx);
+                        if (refract<X>(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick<X>(cosine, m.ref_idx);
                         else reflect_prob = 1.0;
                         nd = (g.next() < reflect_prob) ? reflected : refracted;
                         no = rec.p;
                         nbeta = beta * d3(1.0, 1.0, 1.0); // specular: albedo * color(next), no emission (trace.rs:209-211)
                         done = false;
                     } else if (m.kind == PT_M_METAL) { // src/material.rs:230-241
-                        D3 reflected = reflect(unit_vector(d), rec.n);
+                        D3 reflected = reflect<X>(M<X>::unit_vector(d), rec.n);
                         nd = reflected + m.fuzz * random_in_unit_sphere(g);
                         no = rec.p;
                         nbeta = beta * d3(m.albedo[0], m.albedo[1], m.albedo[2]);
@@ -288,26 +405,27 @@ __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint
                         if (!lambert) (void)random_in_unit_sphere(g);
                         const D3 albedo = texture_value(sv, m.texture, rec.u, rec.v, rec.p);
                         Onb uvw;
-                        if (lambert) uvw = onb_from_w(rec.n);
+                        if (lambert) uvw = onb_from_w<X>(rec.n);
                         // MixturePDF::generate, src/material.rs:427-433
                         D3 dir;
-                        if (g.next() < 0.5) dir = lights_random(sv, g, rec.p);
-                        else dir = lambert ? onb_local(uvw, random_cosine_direction(g)) : d3(0.0, 0.0, 0.0);
+                        if (g.next() < 0.5) dir = lights_random<X>(sv, g, rec.p);
+                        else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : d3(0.0, 0.0, 0.0);
                         // MixturePDF::value, src/material.rs:424-426
+                        const D3 unit_dir = M<X>::unit_vector(dir);
                         double own = 0.0;
                         if (lambert) { // CosinePDF::value, src/material.rs:375-382
-                            double cosine = dot(unit_vector(dir), uvw.w);
+                            double cosine = M<X>::dot(unit_dir, uvw.w);
                             own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
                         }
-                        const double pdf_val = 0.5 * lights_pdf_value(sv, rec.p, dir) + 0.5 * own;
+                        const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir) + 0.5 * own;
                         double spdf = 0.0;
                         if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
-                            double cosine = dot(rec.n, unit_vector(dir));
+                            double cosine = M<X>::dot(rec.n, unit_dir);
                             spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
                         }
                         // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
                         add_radiance(lx, ly, lz, pid, beta * emissive);
-                        nbeta = beta * (albedo * spdf) / pdf_val;
+                        nbeta = M<X>::divs(beta * (albedo * spdf), pdf_val);
                         no = rec.p;
                         nd = dir;
                         done = false;
@@ -391,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_load_rays(const pt_ray *rays, uint32
         q.tm[i] = r.time;
     }
 }
+template <bool X>
 __global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, SceneView sv, const double *hit_t,
                                                        const int32_t *hit_id, pt_hit *out) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -403,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, Scen
             h.prim = -1;
             h.material = -1;
         } else {
-            const HitRec rec = finalize_hit<true>(sv, d3(q.ox[i], q.oy[i], q.oz[i]), d3(q.dx[i], q.dy[i], q.dz[i]),
+            const HitRec rec = finalize_hit<X, true>(sv, d3(q.ox[i], q.oy[i], q.oz[i]), d3(q.dx[i], q.dy[i], q.dz[i]),
                                                   q.tm[i], hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
             h.t = rec.t; h.u = rec.u; h.v = rec.v;
             h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
@@ -465,6 +584,13 @@ struct pt_ctx {
     uint32_t profile_period = 8;
     uint64_t pass_counter = 0;
     std::vector<uint32_t> h_counts;
+
+    // launch shaping
+    bool exact = false;            // PT_CFG_EXACT
+    bool use_scan = false;         // wave-uniform extend for short op streams
+    int scan_max_ops = 96;
+    std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
+    uint32_t profile_n = 0;        // its path count
 };
 
 namespace {
@@ -580,8 +706,45 @@ D3 hunit(D3 a) {
     return D3{a.x / l, a.y / l, a.z / l};
 }
 
-// One wavefront pass over `pp.cpix * pp.s_count` paths.
-int run_pass(pt_ctx *ctx, const PassParams &pp) {
+template <bool X> void launch_extend_x(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
+    if (ctx->use_scan)
+        hipLaunchKernelGGL(k_extend_scan<X>, dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+    else
+        hipLaunchKernelGGL(k_extend<X>, dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+}
+void launch_extend(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
+    if (ctx->exact) launch_extend_x<true>(ctx, grid, q, a);
+    else launch_extend_x<false>(ctx, grid, q, a);
+}
+template <bool X, bool UV>
+void launch_shade_xu(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
+    hipLaunchKernelGGL((k_shade<X, UV>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->d_counts + d,
+                       ctx->d_counts + d + 1, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
+                       ctx->d_l[1], ctx->d_l[2], d, max_depth);
+}
+void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
+    if (ctx->exact) {
+        if (ctx->need_uv) launch_shade_xu<true, true>(ctx, grid, qi, qo, d, max_depth);
+        else launch_shade_xu<true, false>(ctx, grid, qi, qo, d, max_depth);
+    } else {
+        if (ctx->need_uv) launch_shade_xu<false, true>(ctx, grid, qi, qo, d, max_depth);
+        else launch_shade_xu<false, false>(ctx, grid, qi, qo, d, max_depth);
+    }
+}
+
+// Workgroups for bounce d of a pass over n paths. Kernels grid-stride over the device-side queue size, so any
+// grid is correct; the size only matters for speed. Deep bounces hold few rays, and launching the full grid for
+// them costs more than the work itself, so the grid follows the queue sizes seen in the last pass read back.
+int grid_for_bounce(const pt_ctx *ctx, uint32_t n, uint32_t d) {
+    if (ctx->profile.empty() || ctx->profile_n == 0 || d >= ctx->profile.size()) return grid_for(ctx, n);
+    const double scale = (double)n / (double)ctx->profile_n;
+    const uint64_t guess = (uint64_t)(1.25 * scale * (double)ctx->profile[d]) + 2048;
+    return grid_for(ctx, std::min<uint64_t>(guess, n));
+}
+
+// One wavefront pass over `pp.cpix * pp.s_count` paths. `read_counts` copies the per-bounce queue sizes back
+// (one stream synchronisation) to shape the grids of the following passes.
+int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const uint32_t n = pp.cpix * pp.s_count;
     const bool realtime = pp.mode == PT_MODE_REALTIME;
     const bool profile = (ctx->flags & PT_CFG_PROFILE_STAGES) && (ctx->pass_counter % ctx->profile_period == 0);
@@ -613,23 +776,23 @@ int run_pass(pt_ctx *ctx, const PassParams &pp) {
     for (uint32_t d = 0; d < iters; ++d) {
         const Queue &qi = ctx->q[d & 1];
         const Queue &qo = ctx->q[(d + 1) & 1];
+        const int g_d = grid_for_bounce(ctx, n, d);
+        ExtendArgs ea;
+        ea.count_ptr = ctx->d_counts + d;
+        ea.t_min = 0.001; // src/trace.rs:205
+        ea.t_max = kF64Max;
+        ea.keys = ctx->d_keys;
+        ea.medium_seed = 0;
+        ea.key_mode = 0;
+        ea.depth = d;
+        ea.hit_t = ctx->d_hit_t;
+        ea.hit_id = ctx->d_hit_id;
+        ea.counters = count ? ctx->d_trav : nullptr;
         HIP_TRY(ctx, mark());
-        if (count)
-            hipLaunchKernelGGL((k_extend<0, true>), dim3(g_all), dim3(kBlock), 0, st, qi, ctx->d_counts + d, ctx->view,
-                               0.001, kF64Max, ctx->d_keys, 0ull, d, ctx->d_hit_t, ctx->d_hit_id, ctx->d_trav);
-        else
-            hipLaunchKernelGGL((k_extend<0, false>), dim3(g_all), dim3(kBlock), 0, st, qi, ctx->d_counts + d, ctx->view,
-                               0.001, kF64Max, ctx->d_keys, 0ull, d, ctx->d_hit_t, ctx->d_hit_id, ctx->d_trav);
+        launch_extend(ctx, g_d, qi, ea);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
-        if (ctx->need_uv)
-            hipLaunchKernelGGL(k_shade<true>, dim3(g_all), dim3(kBlock), 0, st, qi, qo, ctx->d_counts + d,
-                               ctx->d_counts + d + 1, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
-                               ctx->d_l[1], ctx->d_l[2], d, pp.max_depth);
-        else
-            hipLaunchKernelGGL(k_shade<false>, dim3(g_all), dim3(kBlock), 0, st, qi, qo, ctx->d_counts + d,
-                               ctx->d_counts + d + 1, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
-                               ctx->d_l[1], ctx->d_l[2], d, pp.max_depth);
+        launch_shade(ctx, g_d, qi, qo, d, pp.max_depth);
         HIP_TRY(ctx, mark());
     }
     HIP_TRY(ctx, mark());
@@ -643,11 +806,15 @@ int run_pass(pt_ctx *ctx, const PassParams &pp) {
     ctx->stats.launches_extend += iters;
     ctx->stats.launches_shade += iters;
     ctx->stats.launches_resolve += 1;
-    if (profile) {
+    if (profile || read_counts) {
         ctx->h_counts.resize(iters + 1);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts.data(), ctx->d_counts, (iters + 1) * sizeof(uint32_t),
                                     hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        ctx->profile = ctx->h_counts;
+        ctx->profile_n = n;
+    }
+    if (profile) {
         auto elapsed = [&](size_t a) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ctx->events[a], ctx->events[a + 1]);
@@ -688,6 +855,8 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     ctx->device = cfg->device;
     ctx->seed = cfg->seed;
     ctx->flags = cfg->flags;
+    ctx->exact = (cfg->flags & PT_CFG_EXACT) != 0;
+    if (const char *e = std::getenv("PTGPU_SCAN_MAX_OPS")) ctx->scan_max_ops = (int)std::strtol(e, nullptr, 10);
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;
     if (const char *e = std::getenv("PTGPU_PROFILE_PERIOD")) {
@@ -766,6 +935,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     ctx->need_uv = false;
     for (int i = 0; i < scene->n_textures; ++i)
         if (scene->textures[i].kind == PT_T_IMAGE) ctx->need_uv = true;
+    ctx->use_scan = f.n_traversal_ops <= ctx->scan_max_ops;
+    ctx->profile.clear();
+    ctx->profile_n = 0;
     ctx->have_scene = true;
     return PT_OK;
 }
@@ -840,6 +1012,7 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
     const uint32_t rows_per_chunk = std::max<uint32_t>(1, std::min<uint32_t>(th, ctx->capacity / tw));
     rc = ensure_acc(ctx, (size_t)rows_per_chunk * tw);
     if (rc != PT_OK) return rc;
+    bool first_of_call = true;
     for (uint32_t r0 = 0; r0 < th; r0 += rows_per_chunk) {
         const uint32_t rows = std::min(rows_per_chunk, th - r0);
         PassParams pp;
@@ -861,7 +1034,8 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
             pp.s_count = std::min(s_per_pass, a->spp - s0);
             pp.first_pass = s0 == 0;
             pp.last_pass = s0 + pp.s_count >= a->spp;
-            rc = run_pass(ctx, pp);
+            rc = run_pass(ctx, pp, first_of_call);
+            first_of_call = false;
             if (rc != PT_OK) return rc;
         }
     }
@@ -901,17 +1075,19 @@ static int intersect_common(pt_ctx *ctx, size_t n, double t_min, double t_max, u
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     const int g = grid_for(ctx, n);
+    ExtendArgs ea;
+    ea.count_ptr = ctx->d_counts;
+    ea.t_min = t_min;
+    ea.t_max = t_max;
+    ea.keys = ctx->d_keys;
+    ea.medium_seed = medium_seed;
+    ea.key_mode = 1;
+    ea.depth = 0;
+    ea.hit_t = ctx->d_hit_t;
+    ea.hit_id = ctx->d_hit_id;
+    ea.counters = count ? ctx->d_trav : nullptr;
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    for (int r = 0; r < repeats; ++r) {
-        if (count)
-            hipLaunchKernelGGL((k_extend<1, true>), dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], ctx->d_counts,
-                               ctx->view, t_min, t_max, ctx->d_keys, medium_seed, 0u, ctx->d_hit_t, ctx->d_hit_id,
-                               ctx->d_trav);
-        else
-            hipLaunchKernelGGL((k_extend<1, false>), dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], ctx->d_counts,
-                               ctx->view, t_min, t_max, ctx->d_keys, medium_seed, 0u, ctx->d_hit_t, ctx->d_hit_id,
-                               ctx->d_trav);
-    }
+    for (int r = 0; r < repeats; ++r) launch_extend(ctx, g, ctx->q[0], ea);
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
@@ -950,8 +1126,12 @@ int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double
                            ctx->q[0]);
         rc = intersect_common(ctx, n, t_min, t_max, medium_seed, 1, nullptr);
         if (rc != PT_OK) break;
-        hipLaunchKernelGGL(k_store_hits, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], (uint32_t)n, ctx->view,
-                           ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)d_hits);
+        if (ctx->exact)
+            hipLaunchKernelGGL(k_store_hits<true>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], (uint32_t)n,
+                               ctx->view, ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)d_hits);
+        else
+            hipLaunchKernelGGL(k_store_hits<false>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], (uint32_t)n,
+                               ctx->view, ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)d_hits);
         if (hipMemcpyAsync(out, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             rc = set_error(ctx, PT_ERR_HIP, "D2H hits");

@@ -22,6 +22,20 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    """Default (fast-math) context."""
     ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 20)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_exact():
+    """Exact-arithmetic context (PT_CFG_EXACT): IEEE division, no FMA, f64 sin/cos."""
+    ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 20, flags=ptgpu.PT_CFG_EXACT)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(params=["fast", "exact"])
+def any_ctx(request, gpu_ctx, gpu_ctx_exact):
+    return (gpu_ctx, False) if request.param == "fast" else (gpu_ctx_exact, True)

@@ -34,7 +34,8 @@ def _compare_hits(gpu, ref):
 
 
 @pytest.mark.parametrize("name", SCENES_SMALL)
-def test_extend_parity(gpu_ctx, name):
+def test_extend_parity(any_ctx, name):
+    gpu_ctx, exact = any_ctx
     scene = ptgpu.Scene.named(name, 1.0)
     gpu_ctx.upload(scene)
     w = h = 64
@@ -44,10 +45,14 @@ def test_extend_parity(gpu_ctx, name):
         frac, max_rel, both = _compare_hits(got, ref)
         assert frac >= 0.9999, f"{name}: primitive ids agree on {frac:.6f} of rays"
         assert max_rel <= 1e-4, f"{name}: max relative t error {max_rel:.3e}"
-        # f64 device arithmetic in the reference's order: the records agree to rounding, not just to the bar
-        assert max_rel <= 1e-12
+        # f64 device arithmetic: the records agree to rounding, not just to the bar. Exact mode repeats the
+        # reference's operation order; fast mode differs by a few ulp per operation (cancellation in the
+        # sphere discriminant amplifies that for grazing hits).
+        assert max_rel <= (1e-12 if exact else 1e-7), f"{name}: max relative t error {max_rel:.3e}"
         for field in ("p", "normal"):
-            assert np.allclose(got[field][both], ref[field][both], rtol=1e-9, atol=1e-9), field
+            assert np.allclose(got[field][both], ref[field][both], rtol=1e-6, atol=1e-6), field
+            if exact:
+                assert np.allclose(got[field][both], ref[field][both], rtol=1e-9, atol=1e-9), field
         uv_ok = np.isclose(got["u"][both], ref["u"][both], rtol=1e-9, atol=1e-9, equal_nan=True) & \
                 np.isclose(got["v"][both], ref["v"][both], rtol=1e-9, atol=1e-9, equal_nan=True)
         assert uv_ok.mean() >= 0.9999
@@ -56,7 +61,8 @@ def test_extend_parity(gpu_ctx, name):
 
 @pytest.mark.parametrize("name,spp,depth", [("cornell_box", 4, 50), ("random_scene", 2, 50), ("cornell_smoke", 2, 50),
                                             ("final_book_two", 2, 10), ("simple_light", 2, 10)])
-def test_render_parity_small(gpu_ctx, name, spp, depth):
+def test_render_parity_small(any_ctx, name, spp, depth):
+    gpu_ctx, exact = any_ctx
     scene = ptgpu.Scene.named(name, 1.0)
     gpu_ctx.upload(scene)
     w = h = 48
@@ -66,11 +72,12 @@ def test_render_parity_small(gpu_ctx, name, spp, depth):
     ref = ref[..., :3].astype(np.float64)
     nan_same = (np.isnan(got) == np.isnan(ref)).mean()
     finite = np.isfinite(got) & np.isfinite(ref)
-    close = np.isclose(got, ref, rtol=1e-5, atol=1e-7) | ~finite
-    # same RNG streams, same f64 arithmetic: nearly every pixel is identical; a few paths may take a different
-    # branch where libm results differ in the last bit
+    # same RNG streams, f64 geometry: nearly every pixel follows the same paths as the oracle. Exact mode agrees
+    # to 1e-5 per channel; fast mode samples directions with f32 sin/cos, so its radiance differs by ~1e-6 relative
+    # per bounce and a few more paths flip a hit/miss decision.
+    close = np.isclose(got, ref, rtol=1e-5 if exact else 2e-3, atol=1e-7 if exact else 1e-5) | ~finite
     assert nan_same >= 0.995, f"{name}: NaN masks agree on {nan_same:.4f}"
-    assert close.mean() >= 0.99, f"{name}: {close.mean():.4f} of channels agree to 1e-5"
+    assert close.mean() >= (0.99 if exact else 0.97), f"{name}: {close.mean():.4f} of channels agree"
     rmse = np.sqrt(np.mean((got[finite] - ref[finite]) ** 2))
     scale = max(np.sqrt(np.mean(ref[finite] ** 2)), 1e-12)
     assert rmse / scale <= 0.05, f"{name}: relative RMSE {rmse / scale:.3e}"
