@@ -24,13 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-STRIPE_ROWS = 64
 SEED = 0x5EED0001
-
-
-def stripes_for(rank, world, height):
-    n_stripes = (height + STRIPE_ROWS - 1) // STRIPE_ROWS
-    return [(s * STRIPE_ROWS, min((s + 1) * STRIPE_ROWS, height)) for s in range(n_stripes) if s % world == rank]
 
 
 def algorithmic_bytes(V, P):
@@ -98,6 +92,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pt = importlib.import_module("path-tracer_amd")
+    tiles = importlib.import_module("path-tracer_amd.tiles")
+    STRIPE_ROWS = tiles.STRIPE_ROWS
     W, H = args.width, args.height
     scene = pt.Scene.named(args.scene, W / H, seed=SEED)
     ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight,
@@ -107,12 +103,10 @@ def main():
     # The image lives in a torch tensor so that RCCL can move it; the library renders straight into it.
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     ctx.bind_image(image.data_ptr(), W, H)
-    my_stripes = stripes_for(rank, world, H)
-    n_mine = len(my_stripes)
-    max_stripes = (len(stripes_for(0, world, H)))
+    my_stripes = tiles.stripes_for(rank, world, H)
     pack = gather_list = None
     if world > 1:
-        pack = torch.zeros((max_stripes, STRIPE_ROWS, W, 4), dtype=torch.float32, device=image.device)
+        pack = torch.zeros((tiles.max_stripes(world, H), STRIPE_ROWS, W, 4), dtype=torch.float32, device=image.device)
         if rank == 0:
             gather_list = [torch.zeros_like(pack) for _ in range(world)]
 
@@ -122,13 +116,7 @@ def main():
             return
         for (y0, y1) in my_stripes:
             ctx.render(W, H, args.spp, args.max_depth, tile=(0, y0, W, y1), frame=frame)
-        for k, (y0, y1) in enumerate(my_stripes):
-            pack[k, : y1 - y0].copy_(image[y0:y1])
-        dist.gather(pack, gather_list, dst=0)
-        if rank == 0:
-            for r in range(1, world):
-                for k, (y0, y1) in enumerate(stripes_for(r, world, H)):
-                    image[y0:y1].copy_(gather_list[r][k, : y1 - y0])
+        tiles.gather_stripes(image, rank, world, dist, pack=pack, gather_list=gather_list)
 
     def barrier():
         if dist is not None:

@@ -1144,7 +1144,7 @@ int oracle_rotate_y_box(const double mn[3], const double mx[3], double degrees, 
 
 /* BvhNode::from_list (bvh.rs:13-69) over `nodes`, appending BVH nodes in post-order (left subtree, right subtree,
  * self). New node k gets index desc->n_hitables + k. Writes (left, right) to lr_out[2k..] and the box to
- * box_out[6k..]; returns the number of BVH nodes created (capacity must be >= n).  The comparator
+ * box_out[6k..]; returns the number of BVH nodes created (capacity must be >= 2n: singleton sub-lists get their own node).  The comparator
  * "a.min < b.min ? Less : Greater" is applied with a stable sort; the axis draw floor(3*rand) comes from the
  * scene stream (key derived from `seed`, `*draws` draws already consumed). */
 struct BvhBuild {

@@ -159,8 +159,9 @@ def aabb_hit(mn, mx, origin, direction, tmin, tmax):
 
 def bvh_from_list(desc, nodes, time0, time1, seed, draws=0):
     n = len(nodes)
-    lr = (C.c_int32 * (2 * n))()
-    box = (C.c_double * (6 * n))()
+    cap = 2 * n + 2  # singleton sub-lists get a node of their own (src/bvh.rs:47-49), so nodes can outnumber leaves
+    lr = (C.c_int32 * (2 * cap))()
+    box = (C.c_double * (6 * cap))()
     d = C.c_uint64(draws)
     arr = (C.c_int32 * n)(*nodes)
     created = lib.oracle_bvh_from_list(C.byref(desc), arr, n, time0, time1, C.c_uint64(seed), C.byref(d), lr, box)

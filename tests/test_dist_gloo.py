@@ -1,0 +1,62 @@
+"""Multi-process path on CPU: two ranks over the gloo backend each produce their stripes of the image and the
+stripes are gathered to rank 0 with the same code bench.py uses over RCCL. The per-rank "render" is the CPU oracle
+restricted to the rank's tile rectangles, so the assembled image must equal a single-process render bit for bit
+(the RNG is keyed by global pixel and sample, never by rank)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP, DEPTH, ROWS = 24, 40, 2, 8, 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pt = importlib.import_module("path-tracer_amd")
+    tiles = importlib.import_module("path-tracer_amd.tiles")
+    import oracle_binding as ob
+
+    scene = pt.Scene.named("cornell_box", W / H)
+    image = np.zeros((H, W, 4), dtype=np.float32)
+    for (y0, y1) in tiles.stripes_for(rank, world, H, ROWS):
+        ob.render(scene.desc(), scene.camera, W, H, SPP, DEPTH, tile=(0, y0, W, y1), threads=1, image=image)
+    t = torch.from_numpy(image)
+    tiles.gather_stripes(t, rank, world, dist, rows=ROWS)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stripe_gather_matches_single_process(tmp_path, world):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import ptgpu
+
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    scene = ptgpu.Scene.named("cornell_box", W / H)
+    ref, _ = ob.render(scene.desc(), scene.camera, W, H, SPP, DEPTH, threads=1)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert np.nanmax(ref) > 0

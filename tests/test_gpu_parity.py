@@ -92,3 +92,123 @@ def test_segments_match_oracle(gpu_ctx):
     _, ost = ob.render(scene.desc(), scene.camera, 32, 32, 4, 50, seed=gpu_ctx.seed, threads=4)
     assert st.paths == ost.paths == 32 * 32 * 4
     assert abs(int(st.segments) - int(ost.segments)) <= max(4, ost.segments // 1000)
+
+
+def test_extend_matches_committed_golden(gpu_ctx_exact):
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_extend_4096.npz"))
+    scene = ptgpu.Scene.named("cornell_box", 1.0, seed=int(g["seed"]))
+    gpu_ctx_exact.upload(scene)
+    rays = np.zeros(g["origin"].shape[0], dtype=ptgpu.RAY_DTYPE)
+    rays["origin"], rays["direction"], rays["time"] = g["origin"], g["direction"], g["time"]
+    hits = gpu_ctx_exact.intersect(rays)
+    assert (hits["prim"] == g["prim"]).mean() >= 0.9999
+    both = (g["prim"] >= 0) & (hits["prim"] == g["prim"])
+    assert np.max(np.abs(hits["t"][both] - g["t"][both]) / np.abs(g["t"][both])) <= 1e-12
+
+
+def test_image_matches_committed_golden(any_ctx):
+    import os
+
+    ctx, exact = any_ctx
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_image_32x32_8spp.npz"))
+    scene = ptgpu.Scene.named("cornell_box", 1.0, seed=int(g["seed"]))
+    ctx.upload(scene)
+    ctx.render(32, 32, 8, 50)
+    got = ctx.readback()[..., :3]
+    close = np.isclose(got, g["rgb"], rtol=1e-5 if exact else 2e-3, atol=1e-7 if exact else 1e-5)
+    assert close.mean() >= (0.99 if exact else 0.97)
+
+
+def test_tile_renders_compose_to_the_full_image(gpu_ctx):
+    """Rendering the image as separate tile jobs (src/lib.rs:380-394) gives the same pixels as one job: paths are
+    keyed by global pixel and sample, not by the job that traces them."""
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    gpu_ctx.upload(scene)
+    w, h = 40, 36
+    gpu_ctx.reset()
+    gpu_ctx.render(w, h, 3, 20)
+    full = gpu_ctx.readback().copy()
+    gpu_ctx.reset()
+    for (x0, y0, x1, y1) in [(0, 0, 17, 20), (17, 0, 40, 20), (0, 20, 40, 36)]:
+        gpu_ctx.render(w, h, 3, 20, tile=(x0, y0, x1, y1))
+    tiled = gpu_ctx.readback()
+    assert np.array_equal(full, tiled, equal_nan=True)
+    assert (full[..., 3] == 0).all()        # alpha is never written (src/trace.rs:175-181)
+
+
+def test_small_paths_in_flight_budget_gives_identical_image():
+    """Chunking (rows per pass, samples per pass) is invisible in the result: the per-pixel sum runs in sample order."""
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    imgs = []
+    for budget in (1 << 20, 2048):
+        ctx = ptgpu.Context(max_paths_in_flight=budget)
+        ctx.upload(scene)
+        ctx.render(48, 40, 5, 12)
+        imgs.append(ctx.readback().copy())
+        ctx.close()
+    assert np.array_equal(imgs[0], imgs[1], equal_nan=True)
+
+
+def test_realtime_mode_matches_oracle(any_ctx):
+    """80 % pixel skip and the 1/n running blend (src/trace.rs:144-177) over several frames."""
+    ctx, exact = any_ctx
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    ctx.upload(scene)
+    w = h = 32
+    ctx.reset()
+    ref = np.zeros((h, w, 4), dtype=np.float32)
+    counts = np.zeros((h, w), dtype=np.uint32)
+    for frame in range(6):
+        ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=frame)
+        ob.render(scene.desc(), scene.camera, w, h, 1, 10, seed=ctx.seed, mode=1, frame=frame, threads=4, image=ref,
+                  counts=counts)
+    got = ctx.readback()
+    touched = counts > 0
+    assert 0.55 < touched.mean() < 0.9          # 1 - 0.8^6 = 0.74 of the pixels have been traced at least once
+    assert (got[~touched][..., :3] == 0).all()
+    close = np.isclose(got[..., :3], ref[..., :3], rtol=1e-5 if exact else 2e-3, atol=1e-6 if exact else 1e-5)
+    assert close.mean() >= (0.99 if exact else 0.97)
+
+
+def test_error_codes(gpu_ctx):
+    fresh = ptgpu.Context(max_paths_in_flight=4096)
+    with pytest.raises(ptgpu.PtError) as e:
+        fresh.render(8, 8, 1, 1)
+    assert e.value.code == ptgpu.PT_ERR_NO_SCENE
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    d = scene.desc()
+    fresh.upload_desc(d)
+    with pytest.raises(ptgpu.PtError) as e:
+        fresh.render(8, 8, 1, 1)
+    assert e.value.code == ptgpu.PT_ERR_NO_CAMERA
+    fresh.set_camera(scene.camera)
+    with pytest.raises(ptgpu.PtError) as e:
+        fresh.render(8, 8, 1, 1, tile=(0, 0, 9, 8))
+    assert e.value.code == ptgpu.PT_ERR_INVALID_ARG
+    with pytest.raises(ptgpu.PtError) as e:
+        fresh.render(8, 8, 0, 1)
+    assert e.value.code == ptgpu.PT_ERR_INVALID_ARG
+    with pytest.raises(ptgpu.PtError) as e:
+        fresh.intersect(np.zeros(5000, dtype=ptgpu.RAY_DTYPE))
+    assert e.value.code == ptgpu.PT_ERR_TOO_LARGE
+    fresh.close()
+
+
+def test_furnace_on_gpu(any_ctx):
+    """Closed emissive Lambertian box: every path runs to max_depth and the mean is the truncated geometric series."""
+    ctx, exact = any_ctx
+    from test_oracle_kat import furnace_scene
+
+    a, e, depth = 0.5, 2.0, 6
+    s, cam = furnace_scene(a, e)
+    ctx.upload(s)
+    ctx.set_camera(cam)
+    ctx.stats_reset()
+    ctx.render(64, 64, 64, depth)
+    img = ctx.readback()
+    st = ctx.stats()
+    expected = a * e * sum(a ** k for k in range(depth + 1))
+    assert st.segments >= 0.99 * st.paths * (depth + 1)
+    assert np.nanmean(img[..., 0]) == pytest.approx(expected, rel=0.02)
