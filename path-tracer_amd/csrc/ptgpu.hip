@@ -161,7 +161,9 @@ struct ExtendArgs {
 
 // Per-lane form: every lane walks the stream on its own index. Used when the stream is long (thousands of ops)
 // and lanes of a wave visit mostly different nodes.
-template <bool X>
+// FRAMES / MEDIA say whether the stream holds ENTER/EXIT or MEDIUM ops at all: without them the ray stays
+// loop-invariant during traversal and the code for those ops is not even compiled in.
+template <bool X, bool FRAMES, bool MEDIA>
 __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, ExtendArgs a) {
     const uint32_t n = *a.count_ptr;
     const bool count = a.counters != nullptr;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, Extend
         const D3 wd = d3(q.dx[i], q.dy[i], q.dz[i]);
         const double time = q.tm[i];
         uint64_t pkey = 0;
-        if (sv.has_medium) pkey = (a.key_mode == 0) ? a.keys[q.pid[i]] : intersect_key(a.medium_seed, i);
+        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid[i]] : intersect_key(a.medium_seed, i);
 
         D3 o = wo, d = wd;
         D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
@@ -189,15 +191,15 @@ __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, Extend
                 else cur = op->skip;
                 continue;
             }
-            if (kind == OP_ENTER) {
+            if (FRAMES && kind == OP_ENTER) {
                 apply_chain<X>(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
                 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-            } else if (kind == OP_EXIT) {
+            } else if (FRAMES && kind == OP_EXIT) {
                 o = wo;
                 d = wd;
                 apply_chain<X>(sv.xforms, op->chain_start, (kword >> 16) & 0xff, o, d);
                 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-            } else if (kind == OP_MEDIUM) {
+            } else if (MEDIA && kind == OP_MEDIUM) {
                 if (count) my_prims += 2;
                 double t;
                 if (medium_hit<X>(sv, *op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t)) {
@@ -252,7 +254,25 @@ __device__ __forceinline__ DevOp load_op_uniform(const DevOp *p) {
     return op;
 }
 
-template <bool X>
+// Fast-mode slab test: same interval arithmetic as AABB::hit, with the per-axis swap written as min/max.
+// (Differs from the reference only when a slab bound is NaN, i.e. the origin lies exactly on a bounding plane
+// and the direction is exactly parallel to it.)
+__device__ __forceinline__ bool aabb_hit_fast(const double *b, D3 o, D3 inv, double tmin, double tmax) {
+    const double x0 = (b[0] - o.x) * inv.x, x1 = (b[3] - o.x) * inv.x;
+    const double y0 = (b[1] - o.y) * inv.y, y1 = (b[4] - o.y) * inv.y;
+    const double z0 = (b[2] - o.z) * inv.z, z1 = (b[5] - o.z) * inv.z;
+    tmin = fmax(tmin, fmin(x0, x1));
+    tmax = fmin(tmax, fmax(x0, x1));
+    bool ok = tmax > tmin; // the reference returns false as soon as tmax <= tmin on any axis
+    tmin = fmax(tmin, fmin(y0, y1));
+    tmax = fmin(tmax, fmax(y0, y1));
+    ok = ok && (tmax > tmin);
+    tmin = fmax(tmin, fmin(z0, z1));
+    tmax = fmin(tmax, fmax(z0, z1));
+    return ok && (tmax > tmin);
+}
+
+template <bool X, bool FRAMES, bool MEDIA>
 __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, ExtendArgs a) {
     const uint32_t n = *a.count_ptr;
     const bool count = a.counters != nullptr;
@@ -262,13 +282,11 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n;
         const uint32_t il = valid ? i : 0u;
-        const D3 wo = d3(q.ox[il], q.oy[il], q.oz[il]);
-        const D3 wd = d3(q.dx[il], q.dy[il], q.dz[il]);
+        D3 o = d3(q.ox[il], q.oy[il], q.oz[il]);
+        D3 d = d3(q.dx[il], q.dy[il], q.dz[il]);
         const double time = q.tm[il];
         uint64_t pkey = 0;
-        if (sv.has_medium) pkey = (a.key_mode == 0) ? a.keys[q.pid[il]] : intersect_key(a.medium_seed, il);
-
-        D3 o = wo, d = wd;
+        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid[il]] : intersect_key(a.medium_seed, il);
         D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
         double closest = a.t_max;
         int32_t best = -1;
@@ -279,43 +297,47 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
             if (__ballot(cur == c) == 0ull) c = wave_min_i32(cur); // nobody wants the next op: jump ahead
             c = __builtin_amdgcn_readfirstlane(c);
             if (c >= end) break;
-            const DevOp op = load_op_uniform(sv.ops + c); // uniform address: scalar loads
-            const int32_t kword = op.kind;
+            const DevOp op = load_op_uniform(sv.ops + c); // uniform address: scalar loads into SGPRs
+            const int32_t kword = __builtin_amdgcn_readfirstlane(op.kind);
             const int kind = kword & 0xff;
             const bool mine = cur == c;
             if (kind == OP_BOX) {
-                if (mine) {
-                    if (count) ++my_nodes;
-                    cur = aabb_hit(op.d, o, inv, a.t_min, closest) ? c + 1 : op.skip;
-                }
-                continue;
-            }
-            if (mine) {
+                if (count && mine) ++my_nodes;
+                bool hit;
+                if constexpr (X) hit = aabb_hit(op.d, o, inv, a.t_min, closest);
+                else hit = aabb_hit_fast(op.d, o, inv, a.t_min, closest);
+                cur = mine ? (hit ? c + 1 : op.skip) : cur;
+            } else if (FRAMES && (kind == OP_ENTER || kind == OP_EXIT)) {
+                D3 no, nd;
                 if (kind == OP_ENTER) {
-                    apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, o, d);
-                    inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-                } else if (kind == OP_EXIT) {
-                    o = wo;
-                    d = wd;
-                    apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, o, d);
-                    inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-                } else if (kind == OP_MEDIUM) {
-                    if (count) my_prims += 2;
-                    double t;
-                    if (medium_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t)) {
-                        closest = t;
-                        best = op.leaf;
-                    }
-                } else {
-                    if (count) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
-                    double t;
-                    int sub;
-                    if (prim_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, t, sub)) {
-                        closest = t;
-                        best = op.leaf | (sub << 28);
-                    }
+                    no = o;
+                    nd = d;
+                } else { // back to the enclosing frame: world ray, then that frame's chain
+                    no = d3(q.ox[il], q.oy[il], q.oz[il]);
+                    nd = d3(q.dx[il], q.dy[il], q.dz[il]);
                 }
-                cur = c + 1;
+                apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, no, nd);
+                if (mine) {
+                    o = no;
+                    d = nd;
+                    inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+                    cur = c + 1;
+                }
+            } else {
+                double t = 0.0;
+                int sub = 0;
+                bool hit;
+                if (MEDIA && kind == OP_MEDIUM) {
+                    if (count && mine) my_prims += 2;
+                    hit = medium_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t);
+                } else {
+                    if (count && mine) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
+                    hit = prim_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, t, sub);
+                }
+                const bool take = mine && hit;
+                closest = take ? t : closest;
+                best = take ? (op.leaf | (sub << 28)) : best;
+                cur = mine ? c + 1 : cur;
             }
         }
         if (valid) {
@@ -706,11 +728,19 @@ D3 hunit(D3 a) {
     return D3{a.x / l, a.y / l, a.z / l};
 }
 
-template <bool X> void launch_extend_x(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
+template <bool X, bool FRAMES, bool MEDIA>
+void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
     if (ctx->use_scan)
-        hipLaunchKernelGGL(k_extend_scan<X>, dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+        hipLaunchKernelGGL((k_extend_scan<X, FRAMES, MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
     else
-        hipLaunchKernelGGL(k_extend<X>, dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+        hipLaunchKernelGGL((k_extend<X, FRAMES, MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+}
+template <bool X> void launch_extend_x(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
+    const bool frames = ctx->view.has_frames != 0, media = ctx->view.has_medium != 0;
+    if (frames && media) launch_extend_xfm<X, true, true>(ctx, grid, q, a);
+    else if (frames) launch_extend_xfm<X, true, false>(ctx, grid, q, a);
+    else if (media) launch_extend_xfm<X, false, true>(ctx, grid, q, a);
+    else launch_extend_xfm<X, false, false>(ctx, grid, q, a);
 }
 void launch_extend(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
     if (ctx->exact) launch_extend_x<true>(ctx, grid, q, a);
@@ -911,7 +941,14 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     // transform / leaf tables are never empty on the device so kernels can index them unconditionally
     std::vector<DevXform> xf = f.xforms;
     if (xf.empty()) xf.push_back(DevXform{0.0, 0.0, 0.0, 0.0, 1.0, 1.0});
-    if ((rc = upload(ctx, &ctx->d_ops, f.ops.data(), f.ops.size())) != PT_OK) return rc;
+    {
+        std::vector<DevOp> ops_padded = f.ops; // one sentinel record so that ops[c + 1] is always readable
+        DevOp sentinel;
+        std::memset(&sentinel, 0, sizeof(sentinel));
+        sentinel.kind = op_pack(OP_EXIT, 0, 0);
+        ops_padded.push_back(sentinel);
+        if ((rc = upload(ctx, &ctx->d_ops, ops_padded.data(), ops_padded.size())) != PT_OK) return rc;
+    }
     if ((rc = upload(ctx, &ctx->d_xforms, xf.data(), xf.size())) != PT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_leaves, f.leaves.data(), f.leaves.size())) != PT_OK) return rc;
     if ((rc = upload(ctx, &ctx->d_lights, f.lights.data(), f.lights.size())) != PT_OK) return rc;
