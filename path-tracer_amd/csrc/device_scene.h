@@ -52,18 +52,29 @@ struct DevXform { // 48 bytes
 };
 static_assert(sizeof(DevXform) == 48, "DevXform must be 48 bytes");
 
-struct DevLeaf { // 96 bytes: what finalising a hit needs beyond the op itself
-    int32_t op;          // op holding the geometry parameters
-    int32_t material;
-    int32_t full_start;  // full chain world -> leaf space
-    int32_t full_count;
-    int32_t prim[6];     // graph node reported as pt_hit.prim ([0] unless BOXPRIM, where it is per face)
+// Everything shading a hit needs, in one record, so that a hit id leads to a single dependent fetch:
+// the primitive's geometry (a copy of its op), its wrapper chain and its material with constant textures
+// already resolved to a colour.
+struct DevLeaf { // 192 bytes
     int32_t kind;        // OpKind of the geometry
     int32_t axis;
+    int32_t mat_kind;    // pt_material_kind
+    int32_t texture;     // texture index when the material's texture is not constant, else -1
+    int32_t full_start;  // full chain world -> leaf space
+    int32_t full_count;
+    int32_t material;    // material index, reported in pt_hit
+    int32_t op;          // op holding the geometry in the traversal stream
+    int32_t prim[6];     // graph node reported as pt_hit.prim ([0] unless BOXPRIM, where it is per face)
+    int32_t pad[2];
+    double g[6];         // geometry parameters (same as DevOp::d)
     double e[3];         // MSPHERE: center_range
-    double pad[3];
+    double albedo[3];    // constant texture colour (LAMBERTIAN / DIFFUSE_LIGHT / ISOTROPIC) or METAL albedo
+    double emissive;     // LAMBERTIAN
+    double ref_idx;      // DIELECTRIC
+    double fuzz;         // METAL
+    double pad2;
 };
-static_assert(sizeof(DevLeaf) == 96, "DevLeaf must be 96 bytes");
+static_assert(sizeof(DevLeaf) == 192, "DevLeaf must be 192 bytes");
 
 enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_SPHERE = 1, LIGHT_RECT = 2 };
 struct DevLight { // 48 bytes: a shape of the light list (src/trace.rs:123-128)

@@ -383,6 +383,25 @@ int flatten_scene(const pt_scene_desc *scene, FlatScene &out, std::string &error
     if (rc != PT_OK) return rc;
     // boundary leaves point at their op once the boundary ops have been appended
     for (size_t i = (size_t)out.n_traversal_ops; i < out.ops.size(); ++i) out.leaves[out.ops[i].leaf].op = (int32_t)i;
+    // inline geometry and material into every leaf record
+    for (DevLeaf &lf : out.leaves) {
+        if (lf.op >= 0 && lf.op < (int32_t)out.ops.size())
+            for (int k = 0; k < 6; ++k) lf.g[k] = out.ops[lf.op].d[k];
+        lf.texture = -1;
+        lf.mat_kind = PT_M_DUMMY;
+        if (lf.material < 0 || lf.material >= scene->n_materials) continue;
+        const pt_material &m = scene->materials[lf.material];
+        lf.mat_kind = m.kind;
+        lf.emissive = m.emissive;
+        lf.ref_idx = m.ref_idx;
+        lf.fuzz = m.fuzz;
+        for (int k = 0; k < 3; ++k) lf.albedo[k] = m.albedo[k];
+        if (m.kind == PT_M_LAMBERTIAN || m.kind == PT_M_DIFFUSE_LIGHT || m.kind == PT_M_ISOTROPIC) {
+            const pt_texture &t = scene->textures[m.texture];
+            if (t.kind == PT_T_CONSTANT) for (int k = 0; k < 3; ++k) lf.albedo[k] = t.colour[k];
+            else lf.texture = m.texture;
+        }
+    }
     return PT_OK;
 }
 

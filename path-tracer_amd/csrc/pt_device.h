@@ -396,8 +396,7 @@ PT_DEV void get_sphere_uv(D3 p, double &u, double &v) { // src/sphere.rs:8-14
 // ray to the primitive's space with the same sequence of operations the traversal used, the record is built
 // there as the primitive's hit() does, then carried back out through the wrappers in reverse.
 template <bool X, bool NEED_UV>
-PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double t, int leaf_id, int sub) {
-    const DevLeaf lf = sv.leaves[leaf_id];
+PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, double t, int sub) {
     apply_chain<X>(sv.xforms, lf.full_start, lf.full_count, o, d);
     HitRec r;
     r.t = t;
@@ -405,28 +404,28 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, D3 o, D3 d, double time, double 
     r.v = 0.0;
     r.mat = lf.material;
     r.prim = lf.prim[0];
-    const DevOp &op = sv.ops[lf.op];
+    const double *g = lf.g;
     D3 point = M<X>::point_at(o, d, t);
     r.p = point;
     if (lf.kind == OP_SPHERE) {
-        D3 c = d3(op.d[0], op.d[1], op.d[2]);
+        D3 c = d3(g[0], g[1], g[2]);
         if (NEED_UV) {
-            if (sub == 0) get_sphere_uv(M<X>::divs(c - point, op.d[3]), r.u, r.v); // sphere.rs:56
+            if (sub == 0) get_sphere_uv(M<X>::divs(c - point, g[3]), r.u, r.v); // sphere.rs:56
             else get_sphere_uv(c - point, r.u, r.v);                               // sphere.rs:69
         }
-        r.n = M<X>::divs(point - c, op.d[3]);
+        r.n = M<X>::divs(point - c, g[3]);
     } else if (lf.kind == OP_MSPHERE) {
-        D3 c = moving_center<X>(op.d, lf.e, time);
+        D3 c = moving_center<X>(g, lf.e, time);
         if (NEED_UV) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
-        r.n = M<X>::divs(point - c, op.d[3]);
+        r.n = M<X>::divs(point - c, g[3]);
     } else if (lf.kind == OP_RECT || lf.kind == OP_BOXPRIM) {
         double amin, amax, bmin, bmax, c;
         int axis;
         if (lf.kind == OP_RECT) {
-            amin = op.d[0]; amax = op.d[1]; bmin = op.d[2]; bmax = op.d[3]; c = op.d[4];
+            amin = g[0]; amax = g[1]; bmin = g[2]; bmax = g[3]; c = g[4];
             axis = lf.axis;
         } else {
-            box_face(op.d, sub, amin, amax, bmin, bmax, c, axis);
+            box_face(g, sub, amin, amax, bmin, bmax, c, axis);
             r.prim = lf.prim[sub];
         }
         if (NEED_UV) {
@@ -639,6 +638,113 @@ template <bool X> PT_DEV D3 lights_random(const SceneView &sv, Rng &g, D3 origin
     return light_random<X>(sv.lights[index], g, origin);
 }
 
+// ------------------------------------------------- f32 radiometry (fast) --
+// In fast mode positions, ray directions and hit distances stay f64, but the quantities that only weight a
+// path -- sampled local directions, cosines, pdf values, albedo * scattering_pdf / pdf -- are evaluated in f32
+// on the single-instruction rcp / rsq / sqrt / sin / cos units. Differences that are cancellation-prone
+// (point - centre, |oc|^2 - r^2) are formed in f64 first and only then narrowed.
+struct F3 {
+    float x, y, z;
+};
+PT_DEV F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+PT_DEV F3 to_f3(D3 a) { return F3{(float)a.x, (float)a.y, (float)a.z}; }
+PT_DEV D3 to_d3(F3 a) { return D3{(double)a.x, (double)a.y, (double)a.z}; }
+PT_DEV F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+PT_DEV float dotf(F3 a, F3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+PT_DEV F3 crossf(F3 a, F3 b) { // src/math/vec3.rs:137-143
+    return F3{a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x};
+}
+PT_DEV F3 unitf(F3 a) { return a * __builtin_amdgcn_rsqf(dotf(a, a)); }
+struct OnbF {
+    F3 u, v, w;
+};
+PT_DEV OnbF onbf_from_w(F3 n) { // src/onb.rs:18-33
+    F3 w = unitf(n);
+    F3 a = __builtin_fabsf(w.x) > 0.9f ? f3(0.f, 1.f, 0.f) : f3(1.f, 0.f, 0.f);
+    F3 v = unitf(crossf(w, a));
+    F3 u = crossf(w, v);
+    return OnbF{u, v, w};
+}
+PT_DEV F3 onbf_local(const OnbF &b, F3 a) {
+    return F3{__builtin_fmaf(b.w.x, a.z, __builtin_fmaf(b.v.x, a.y, b.u.x * a.x)),
+              __builtin_fmaf(b.w.y, a.z, __builtin_fmaf(b.v.y, a.y, b.u.y * a.x)),
+              __builtin_fmaf(b.w.z, a.z, __builtin_fmaf(b.v.z, a.y, b.u.z * a.x))};
+}
+PT_DEV F3 random_cosine_direction_f(Rng &g) { // src/material.rs:10-19
+    const float r1 = (float)g.next();
+    const float r2 = (float)g.next();
+    const float z = __builtin_amdgcn_sqrtf(1.0f - r2);
+    const float r2_sqrt = __builtin_amdgcn_sqrtf(r2);
+    return f3(__builtin_amdgcn_cosf(r1) * r2_sqrt, __builtin_amdgcn_sinf(r1) * r2_sqrt, z);
+}
+// One light shape: Hitable::random (src/sphere.rs:96-101 with 16-25, src/rect.rs:135-144, default hitable.rs:33-35).
+PT_DEV D3 light_random_fast(const DevLight &l, Rng &g, D3 origin) {
+    if (l.kind == LIGHT_SPHERE) {
+        const D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
+        const float distance_sq = (float)squared_length(direction);
+        const OnbF uvw = onbf_from_w(to_f3(direction));
+        const float r1 = (float)g.next();
+        const float r2 = (float)g.next();
+        const float radius = (float)l.d[3];
+        const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(1.0f - radius * radius * __builtin_amdgcn_rcpf(distance_sq)) - 1.0f);
+        const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
+        return to_d3(onbf_local(uvw, f3(__builtin_amdgcn_cosf(r1) * c, __builtin_amdgcn_sinf(r1) * c, z)));
+    }
+    if (l.kind == LIGHT_RECT) {
+        const double random_a = __builtin_fma(g.next(), l.d[1] - l.d[0], l.d[0]);
+        const double random_b = __builtin_fma(g.next(), l.d[3] - l.d[2], l.d[2]);
+        const D3 p = l.axis == 0 ? d3(l.d[4], random_a, random_b)
+                                 : (l.axis == 1 ? d3(random_a, l.d[4], random_b) : d3(random_a, random_b, l.d[4]));
+        return p - origin;
+    }
+    return d3(1.0, 0.0, 0.0);
+}
+// One light shape: Hitable::pdf_value (src/sphere.rs:87-95, src/rect.rs:124-133, default hitable.rs:30-32).
+// `dir` is the f32 copy of the direction, `len2` its squared length.
+PT_DEV float light_pdf_value_fast(const DevLight &l, D3 origin, F3 dir, float len2) {
+    if (l.kind == LIGHT_SPHERE) {
+        const D3 ocd = origin - d3(l.d[0], l.d[1], l.d[2]);
+        const double dsq_d = M<false>::squared_length(ocd);
+        const float cc = (float)__builtin_fma(-l.d[3], l.d[3], dsq_d); // |oc|^2 - r^2 without f32 cancellation
+        const F3 oc = to_f3(ocd);
+        const float b = dotf(oc, dir);
+        const float disc = __builtin_fmaf(-len2, cc, b * b);
+        bool hit = false;
+        if (disc > 0.0f) {
+            const float root = __builtin_amdgcn_sqrtf(disc);
+            const float inv_a = __builtin_amdgcn_rcpf(len2);
+            const float t0 = (-b - root) * inv_a, t1 = (-b + root) * inv_a;
+            hit = (t0 > 0.001f) || (t1 > 0.001f); // t < f64::MAX always holds for finite t
+        }
+        if (!hit) return 0.0f;
+        const float dsq = (float)dsq_d;
+        // 1 - cos_theta_max with cos_theta_max = sqrt(1 - r^2/d^2) = sqrt(cc/d^2), written without cancellation
+        const float inv_dsq = __builtin_amdgcn_rcpf(dsq);
+        const float cos_theta_max = __builtin_amdgcn_sqrtf(cc * inv_dsq);
+        const float one_minus = ((float)(l.d[3] * l.d[3]) * inv_dsq) * __builtin_amdgcn_rcpf(1.0f + cos_theta_max);
+        return __builtin_amdgcn_rcpf(6.2831853071795864769f * one_minus);
+    }
+    if (l.kind == LIGHT_RECT) {
+        const double ok = l.axis == 0 ? origin.x : (l.axis == 1 ? origin.y : origin.z);
+        const float dk = l.axis == 0 ? dir.x : (l.axis == 1 ? dir.y : dir.z);
+        const float t = (float)(l.d[4] - ok) * __builtin_amdgcn_rcpf(dk);
+        if (t < 0.001f || t > 3.0e38f) return 0.0f; // a NaN t passes, as in the reference (src/rect.rs:99)
+        F3 rel; // in-plane coordinates of the hit relative to the rectangle's low corner, formed in f64
+        if (l.axis == 0) rel = f3((float)(origin.y - l.d[0]), (float)(origin.z - l.d[2]), 0.f);
+        else if (l.axis == 1) rel = f3((float)(origin.x - l.d[0]), (float)(origin.z - l.d[2]), 0.f);
+        else rel = f3((float)(origin.x - l.d[0]), (float)(origin.y - l.d[2]), 0.f);
+        const float da = l.axis == 0 ? dir.y : dir.x;
+        const float db = l.axis == 2 ? dir.y : dir.z;
+        const float a = __builtin_fmaf(t, da, rel.x), b = __builtin_fmaf(t, db, rel.y);
+        const float wa = (float)(l.d[1] - l.d[0]), wb = (float)(l.d[3] - l.d[2]);
+        if (a < 0.0f || a > wa || b < 0.0f || b > wb) return 0.0f;
+        const float distance_sq = t * t * len2;
+        const float cosine = __builtin_fabsf(dk * __builtin_amdgcn_rsqf(len2));
+        return distance_sq * __builtin_amdgcn_rcpf(cosine * (wa * wb));
+    }
+    return 0.0f;
+}
+
 // ------------------------------------------------------------- materials --
 template <bool X> PT_DEV D3 reflect(D3 v, D3 n) { return v - (2.0 * M<X>::dot(v, n) * n); } // src/material.rs:50-52
 template <bool X> PT_DEV bool refract(D3 v, D3 n, double ni_over_nt, D3 &refracted) { // src/material.rs:54-64
@@ -661,14 +767,19 @@ template <bool X> PT_DEV double schlick(double cosine, double ref_idx) { // src/
     }
 }
 
+// The material's texture at a hit: the colour inlined in the leaf record, or the general evaluator.
+PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec) {
+    if (lf.texture < 0) return d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
+    return texture_value(sv, lf.texture, rec.u, rec.v, rec.p);
+}
 // Material::emitted (src/material.rs:145-147 default, 303-305 Lambertian, 325-331 DiffuseLight).
-PT_DEV D3 emitted(const SceneView &sv, const pt_material &m, D3 ray_d, const HitRec &rec) {
-    if (m.kind == PT_M_LAMBERTIAN) {
-        if (m.emissive > 0.0) return texture_value(sv, m.texture, rec.u, rec.v, rec.p) * m.emissive;
+PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec) {
+    if (lf.mat_kind == PT_M_LAMBERTIAN) {
+        if (lf.emissive > 0.0) return leaf_texture(sv, lf, rec) * lf.emissive;
         return d3(0.0, 0.0, 0.0);
     }
-    if (m.kind == PT_M_DIFFUSE_LIGHT) {
-        if (dot(rec.n, ray_d) < 0.0) return texture_value(sv, m.texture, rec.u, rec.v, rec.p);
+    if (lf.mat_kind == PT_M_DIFFUSE_LIGHT) {
+        if (dot(rec.n, ray_d) < 0.0) return leaf_texture(sv, lf, rec);
         return d3(0.0, 0.0, 0.0);
     }
     return d3(0.0, 0.0, 0.0);

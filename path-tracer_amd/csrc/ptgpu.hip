@@ -389,12 +389,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
                 Rng g{keys[pid], qi.rn[i]};
-                const HitRec rec = finalize_hit<X, NEED_UV>(sv, o, d, time, hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
-                const pt_material m = sv.materials[rec.mat];
-                const D3 emissive = emitted(sv, m, d, rec);
+                const DevLeaf lf = sv.leaves[id & 0x0fffffff];
+                const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, hit_t[i], (id >> 28) & 7);
+                const D3 emissive = emitted(sv, lf, d, rec);
                 bool done = true;
                 if (depth < max_depth) {
-                    if (m.kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
+                    if (lf.mat_kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
                         D3 outward_normal;
                         D3 reflected = reflect<X>(d, rec.n);
                         double ni_over_nt, reflect_prob, cosine;
@@ -402,54 +402,90 @@ __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint
                         const double d_dot_n = M<X>::dot(d, rec.n);
                         if (d_dot_n > 0.0) {
                             outward_normal = -rec.n;
-                            ni_over_nt = m.ref_idx;
-                            cosine = M<X>::div(m.ref_idx * d_dot_n, M<X>::length(d));
+                            ni_over_nt = lf.ref_idx;
+                            cosine = M<X>::div(lf.ref_idx * d_dot_n, M<X>::length(d));
                         } else {
                             outward_normal = rec.n;
-                            ni_over_nt = M<X>::rcp(m.ref_idx);
+                            ni_over_nt = M<X>::rcp(lf.ref_idx);
                             cosine = M<X>::div(-d_dot_n, M<X>::length(d));
                         }
-                        if (refract<X>(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick<X>(cosine, m.ref_idx);
+                        if (refract<X>(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick<X>(cosine, lf.ref_idx);
                         else reflect_prob = 1.0;
                         nd = (g.next() < reflect_prob) ? reflected : refracted;
                         no = rec.p;
                         nbeta = beta * d3(1.0, 1.0, 1.0); // specular: albedo * color(next), no emission (trace.rs:209-211)
                         done = false;
-                    } else if (m.kind == PT_M_METAL) { // src/material.rs:230-241
+                    } else if (lf.mat_kind == PT_M_METAL) { // src/material.rs:230-241
                         D3 reflected = reflect<X>(M<X>::unit_vector(d), rec.n);
-                        nd = reflected + m.fuzz * random_in_unit_sphere(g);
+                        nd = reflected + lf.fuzz * random_in_unit_sphere(g);
                         no = rec.p;
-                        nbeta = beta * d3(m.albedo[0], m.albedo[1], m.albedo[2]);
+                        nbeta = beta * d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
                         done = false;
-                    } else if (m.kind == PT_M_LAMBERTIAN || m.kind == PT_M_ISOTROPIC) {
-                        const bool lambert = m.kind == PT_M_LAMBERTIAN;
+                    } else if (lf.mat_kind == PT_M_LAMBERTIAN || lf.mat_kind == PT_M_ISOTROPIC) {
+                        const bool lambert = lf.mat_kind == PT_M_LAMBERTIAN;
                         // scatter(): src/material.rs:289-301 (Lambertian), 347-351 (Isotropic draws a sphere sample it never uses)
                         if (!lambert) (void)random_in_unit_sphere(g);
-                        const D3 albedo = texture_value(sv, m.texture, rec.u, rec.v, rec.p);
-                        Onb uvw;
-                        if (lambert) uvw = onb_from_w<X>(rec.n);
-                        // MixturePDF::generate, src/material.rs:427-433
-                        D3 dir;
-                        if (g.next() < 0.5) dir = lights_random<X>(sv, g, rec.p);
-                        else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : d3(0.0, 0.0, 0.0);
-                        // MixturePDF::value, src/material.rs:424-426
-                        const D3 unit_dir = M<X>::unit_vector(dir);
-                        double own = 0.0;
-                        if (lambert) { // CosinePDF::value, src/material.rs:375-382
-                            double cosine = M<X>::dot(unit_dir, uvw.w);
-                            own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
-                        }
-                        const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir) + 0.5 * own;
-                        double spdf = 0.0;
-                        if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
-                            double cosine = M<X>::dot(rec.n, unit_dir);
-                            spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
-                        }
-                        // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
+                        const D3 albedo = leaf_texture(sv, lf, rec);
                         add_radiance(lx, ly, lz, pid, beta * emissive);
-                        nbeta = M<X>::divs(beta * (albedo * spdf), pdf_val);
+                        if constexpr (X) {
+                            Onb uvw;
+                            if (lambert) uvw = onb_from_w<X>(rec.n);
+                            // MixturePDF::generate, src/material.rs:427-433
+                            D3 dir;
+                            if (g.next() < 0.5) dir = lights_random<X>(sv, g, rec.p);
+                            else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : d3(0.0, 0.0, 0.0);
+                            // MixturePDF::value, src/material.rs:424-426
+                            const D3 unit_dir = M<X>::unit_vector(dir);
+                            double own = 0.0;
+                            if (lambert) { // CosinePDF::value, src/material.rs:375-382
+                                double cosine = M<X>::dot(unit_dir, uvw.w);
+                                own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
+                            }
+                            const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir) + 0.5 * own;
+                            double spdf = 0.0;
+                            if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
+                                double cosine = M<X>::dot(rec.n, unit_dir);
+                                spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
+                            }
+                            // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
+                            nbeta = M<X>::divs(beta * (albedo * spdf), pdf_val);
+                            nd = dir;
+                        } else {
+                            // same estimator with the weights in f32 (see "f32 radiometry" in pt_device.h)
+                            const F3 nf = to_f3(rec.n);
+                            OnbF uvw;
+                            if (lambert) uvw = onbf_from_w(nf);
+                            D3 dir;
+                            if (g.next() < 0.5) {
+                                const double x = (double)sv.n_lights * g.next(); // HitableList::random, hitable.rs:74-77
+                                dir = light_random_fast(sv.lights[(int)x], g, rec.p);
+                            } else {
+                                dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(g))) : d3(0.0, 0.0, 0.0);
+                            }
+                            const F3 dirf = to_f3(dir);
+                            const float len2 = dotf(dirf, dirf);
+                            const F3 unit_dir = dirf * __builtin_amdgcn_rsqf(len2);
+                            float own = 0.0f, spdf = 0.0f;
+                            if (lambert) {
+                                const float cw = dotf(unit_dir, uvw.w);
+                                own = cw > 0.0f ? cw * 0.31830988618379067154f : 0.0f;
+                                const float cn = dotf(nf, unit_dir);
+                                spdf = cn < 0.0f ? 0.0f : cn * 0.31830988618379067154f;
+                            }
+                            const float weight = __builtin_amdgcn_rcpf((float)sv.n_lights);
+                            float lsum = 0.0f;
+                            for (int k = 0; k < sv.n_lights; ++k)
+                                lsum += weight * light_pdf_value_fast(sv.lights[k], rec.p, dirf, len2);
+                            const float pdf_val = 0.5f * lsum + 0.5f * own;
+                            const float inv_pdf = __builtin_amdgcn_rcpf(pdf_val);
+                            // 0 * x / 0 must stay NaN (src/trace.rs:217-220): rcp(0) = inf and 0 * inf = NaN
+                            const D3 w = d3((double)(((float)albedo.x * spdf) * inv_pdf),
+                                            (double)(((float)albedo.y * spdf) * inv_pdf),
+                                            (double)(((float)albedo.z * spdf) * inv_pdf));
+                            nbeta = beta * w;
+                            nd = dir;
+                        }
                         no = rec.p;
-                        nd = dir;
                         done = false;
                     }
                 }
@@ -544,8 +580,9 @@ __global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, Scen
             h.prim = -1;
             h.material = -1;
         } else {
-            const HitRec rec = finalize_hit<X, true>(sv, d3(q.ox[i], q.oy[i], q.oz[i]), d3(q.dx[i], q.dy[i], q.dz[i]),
-                                                  q.tm[i], hit_t[i], id & 0x0fffffff, (id >> 28) & 7);
+            const DevLeaf lf = sv.leaves[id & 0x0fffffff];
+            const HitRec rec = finalize_hit<X, true>(sv, lf, d3(q.ox[i], q.oy[i], q.oz[i]),
+                                                     d3(q.dx[i], q.dy[i], q.dz[i]), q.tm[i], hit_t[i], (id >> 28) & 7);
             h.t = rec.t; h.u = rec.u; h.v = rec.v;
             h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
             h.normal[0] = rec.n.x; h.normal[1] = rec.n.y; h.normal[2] = rec.n.z;
