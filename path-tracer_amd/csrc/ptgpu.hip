@@ -29,7 +29,18 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kDefaultPathsInFlight = 1u << 22;
-constexpr int kMaxDepthSlots = 1024; // counts[] entries; max_depth is capped at kMaxDepthSlots - 2
+constexpr int kMaxDepthSlots = 1024; // bounce slots of counts[]; max_depth is capped at kMaxDepthSlots - 2
+constexpr uint32_t kShards = 64;     // queue shards (power of two)
+
+// A queue is cut into `shards` equal regions with a fill count each. Chunk j of 256 paths lives in shard
+// j % shards, and a path stays in its shard for life, so compaction is per shard: the one atomic a workgroup
+// issues per chunk goes to one of 64 counters instead of a single hot word, and a shard can never overflow
+// (paths only die). Consumers walk "virtual chunks" (row c, shard s) up to the fullest shard's row count.
+struct QueueShape {
+    uint32_t shards;    // power of two, <= 64
+    uint32_t shift;     // log2(shards)
+    uint32_t shard_cap; // slots per shard, multiple of kBlock
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // Path-state queues (structure of arrays, one entry per in-flight ray)
@@ -93,36 +104,56 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *out_count
     return slot;
 }
 
+// Largest fill count over the shards of a queue (every lane of every wave gets the value).
+__device__ __forceinline__ uint32_t max_shard_count(const uint32_t *counts, uint32_t shards) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t v = lane < shards ? counts[lane] : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+        v = o > v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // raygen
 // ------------------------------------------------------------------------------------------------------------
 template <bool REALTIME>
-__global__ __launch_bounds__(kBlock) void k_raygen(Queue q, uint64_t *keys, double *lx, double *ly, double *lz,
-                                                   CameraDev cam, PassParams pp, uint32_t *counts) {
+__global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, uint64_t *keys, double *lx, double *ly,
+                                                   double *lz, CameraDev cam, PassParams pp, uint32_t *counts) {
     __shared__ uint32_t lds[kWavesPerBlock + 1];
     const uint32_t n = pp.cpix * pp.s_count;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t pid = base + threadIdx.x;
+    const uint32_t n_chunks = (n + kBlock - 1) / kBlock;
+    for (uint32_t j = blockIdx.x; j < n_chunks; j += gridDim.x) {
+        const uint32_t s_id = j & (sh.shards - 1), row = j >> sh.shift;
+        const uint32_t pid = j * kBlock + threadIdx.x;
         bool alive = pid < n;
-        uint32_t i = 0, j = 0, s = 0;
+        uint32_t i = 0, jy = 0, s = 0;
         uint64_t pixel = 0;
         if (alive) {
             const uint32_t p = pid % pp.cpix;
             s = pid / pp.cpix;
             i = pp.cx0 + p % pp.cw;
-            j = pp.cy0 + p / pp.cw;
-            pixel = (uint64_t)j * pp.width + i;
+            jy = pp.cy0 + p / pp.cw;
+            pixel = (uint64_t)jy * pp.width + i;
             if (REALTIME) alive = !(pixel_skip_draw(pp.seed, pp.frame, pixel) < 0.8); // src/trace.rs:144
         }
-        uint32_t slot = pid;
-        if (REALTIME) slot = compact_slot(alive, &counts[0], lds);
+        uint32_t local = row * kBlock + threadIdx.x;
+        if (REALTIME) {
+            local = compact_slot(alive, &counts[s_id], lds);
+        } else if (threadIdx.x == 0) {
+            const uint32_t left = n - j * kBlock;
+            atomicAdd(&counts[s_id], left < (uint32_t)kBlock ? left : (uint32_t)kBlock);
+        }
+        const uint32_t slot = s_id * sh.shard_cap + local;
         if (alive) {
             Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
             // src/trace.rs:153-156
             double random = g.next();
             const double u = ((double)i + random) / (double)pp.width;
             random = g.next();
-            const double v = ((double)j + random) / (double)pp.height;
+            const double v = ((double)jy + random) / (double)pp.height;
             // Camera::get_ray, src/camera.rs:53-59
             D3 rd = random_in_unit_disk(g) * cam.lens_radius;
             D3 offset = cam.u * rd.x + cam.v * rd.y;
@@ -141,14 +172,14 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, uint64_t *keys, doub
             lx[pid] = 0.0; ly[pid] = 0.0; lz[pid] = 0.0;
         }
     }
-    if (!REALTIME && blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // extend: stackless traversal of the threaded op stream
 // ------------------------------------------------------------------------------------------------------------
 struct ExtendArgs {
-    const uint32_t *count_ptr;
+    const uint32_t *counts; // fill count per shard of the queue
+    QueueShape sh;
     double t_min, t_max;
     const uint64_t *keys;  // key_mode 0: the path's key is keys[pid[i]] (render)
     uint64_t medium_seed;  // key_mode 1: intersect_key(medium_seed, i) (pt_intersect)
@@ -165,10 +196,14 @@ struct ExtendArgs {
 // loop-invariant during traversal and the code for those ops is not even compiled in.
 template <bool X, bool FRAMES, bool MEDIA>
 __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, ExtendArgs a) {
-    const uint32_t n = *a.count_ptr;
     const bool count = a.counters != nullptr;
     unsigned long long my_nodes = 0, my_prims = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t n_virtual = ((max_shard_count(a.counts, a.sh.shards) + kBlock - 1) / kBlock) << a.sh.shift;
+    for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+        const uint32_t s_id = v & (a.sh.shards - 1);
+        const uint32_t local = (v >> a.sh.shift) * kBlock + threadIdx.x;
+        if (local >= a.counts[s_id]) continue;
+        const uint32_t i = s_id * a.sh.shard_cap + local;
         const D3 wo = d3(q.ox[i], q.oy[i], q.oz[i]);
         const D3 wd = d3(q.dx[i], q.dy[i], q.dz[i]);
         const double time = q.tm[i];
@@ -274,14 +309,19 @@ __device__ __forceinline__ bool aabb_hit_fast(const double *b, D3 o, D3 inv, dou
 
 template <bool X, bool FRAMES, bool MEDIA>
 __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, ExtendArgs a) {
-    const uint32_t n = *a.count_ptr;
     const bool count = a.counters != nullptr;
     unsigned long long my_nodes = 0, my_prims = 0;
     const int32_t end = sv.n_traversal_ops;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const bool valid = i < n;
-        const uint32_t il = valid ? i : 0u;
+    const uint32_t n_virtual = ((max_shard_count(a.counts, a.sh.shards) + kBlock - 1) / kBlock) << a.sh.shift;
+    for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+        const uint32_t s_id = v & (a.sh.shards - 1);
+        const uint32_t ns = a.counts[s_id];
+        const uint32_t row0 = (v >> a.sh.shift) * kBlock;
+        if (row0 >= ns) continue;
+        const uint32_t local = row0 + threadIdx.x;
+        const bool valid = local < ns;
+        const uint32_t i = s_id * a.sh.shard_cap + local;
+        const uint32_t il = valid ? i : s_id * a.sh.shard_cap;
         D3 o = d3(q.ox[il], q.oy[il], q.oz[il]);
         D3 d = d3(q.dx[il], q.dy[il], q.dz[il]);
         const double time = q.tm[il];
@@ -365,14 +405,20 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
 }
 
 template <bool X, bool NEED_UV>
-__global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint32_t *n_in, uint32_t *n_out,
-                                                  SceneView sv, const double *hit_t, const int32_t *hit_id,
+__global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
+                                                  uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   const uint64_t *keys, double *lx, double *ly, double *lz,
                                                   uint32_t depth, uint32_t max_depth) {
     __shared__ uint32_t lds[kWavesPerBlock + 1];
-    const uint32_t n = *n_in;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t i = base + threadIdx.x;
+    const uint32_t n_virtual = ((max_shard_count(n_in, sh.shards) + kBlock - 1) / kBlock) << sh.shift;
+    for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+        const uint32_t s_id = v & (sh.shards - 1);
+        const uint32_t ns = n_in[s_id];
+        const uint32_t row0 = (v >> sh.shift) * kBlock;
+        if (row0 >= ns) continue; // uniform for the workgroup
+        const uint32_t local = row0 + threadIdx.x;
+        const uint32_t i = s_id * sh.shard_cap + local;
+        const uint32_t n = s_id * sh.shard_cap + ns; // first slot past this shard's entries
         bool alive = false;
         D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
         double time = 0.0;
@@ -494,7 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, const uint
                 rn = g.n;
             }
         }
-        const uint32_t slot = compact_slot(alive, n_out, lds);
+        const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], lds);
         if (alive) {
             qo.ox[slot] = no.x; qo.oy[slot] = no.y; qo.oz[slot] = no.z;
             qo.dx[slot] = nd.x; qo.dy[slot] = nd.y; qo.dz[slot] = nd.z;
@@ -549,10 +595,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const doub
         }
         if (px[0] != px[0] || px[1] != px[1] || px[2] != px[2]) atomicAdd(&stats[1], 1ull);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0) { // segments traced in this pass = sum of every bounce's queue fill
         unsigned long long seg = 0;
-        for (uint32_t k = 0; k <= pp.max_depth; ++k) seg += counts[k];
-        atomicAdd(&stats[0], seg);
+        const uint32_t total = (pp.max_depth + 1) * kShards;
+        for (uint32_t k = threadIdx.x; k < total; k += kBlock) seg += counts[k];
+        if (seg) atomicAdd(&stats[0], seg);
     }
 }
 
@@ -603,7 +650,8 @@ struct pt_ctx {
     int device = 0;
     uint64_t seed = 0;
     uint32_t flags = 0;
-    uint32_t capacity = 0; // paths in flight
+    uint32_t capacity = 0; // paths in flight (rounded up to whole shards)
+    QueueShape shape{};    // sharded layout of the render queues
     hipStream_t stream = nullptr;
     std::string error;
     int n_cu = 256;
@@ -642,7 +690,7 @@ struct pt_ctx {
     std::vector<hipEvent_t> events;
     uint32_t profile_period = 8;
     uint64_t pass_counter = 0;
-    std::vector<uint32_t> h_counts;
+    std::vector<uint32_t> h_counts, h_shard_counts;
 
     // launch shaping
     bool exact = false;            // PT_CFG_EXACT
@@ -688,6 +736,21 @@ int grid_for(const pt_ctx *ctx, uint64_t n) {
 }
 
 int alloc_path_state(pt_ctx *ctx) {
+    // whole shards of whole workgroup chunks
+    uint32_t shards = 8, shift = 3; // measured: 64 shards cost 18 % (scattered streams), 8 cost 2 % and leave 8x atomic headroom
+    if (const char *e = std::getenv("PTGPU_SHARDS")) { // 1, 2, 4, ... 64
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= (long)kShards && (v & (v - 1)) == 0) {
+            shards = (uint32_t)v;
+            shift = 0;
+            while ((1u << shift) < shards) ++shift;
+        }
+    }
+    const uint32_t per_shard = ((ctx->capacity + kBlock * shards - 1) / (kBlock * shards)) * kBlock;
+    ctx->capacity = per_shard * shards;
+    ctx->shape.shards = shards;
+    ctx->shape.shift = shift;
+    ctx->shape.shard_cap = per_shard;
     const size_t n = ctx->capacity;
     // 2 queues x (10 f64 + 2 u32) + keys + 3 f64 radiance + hit (f64 + i32)
     const size_t per_path = 2 * (10 * 8 + 2 * 4) + 8 + 3 * 8 + 8 + 4;
@@ -713,7 +776,7 @@ int alloc_path_state(pt_ctx *ctx) {
     for (int k = 0; k < 3; ++k) ctx->d_l[k] = (double *)take(n * 8);
     ctx->d_hit_t = (double *)take(n * 8);
     ctx->d_hit_id = (int32_t *)take(n * 4);
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_counts, kMaxDepthSlots * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)kMaxDepthSlots * kShards * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stats, 2 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_trav, sizeof(TraversalCounters)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -785,8 +848,8 @@ void launch_extend(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
 }
 template <bool X, bool UV>
 void launch_shade_xu(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
-    hipLaunchKernelGGL((k_shade<X, UV>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->d_counts + d,
-                       ctx->d_counts + d + 1, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
+    hipLaunchKernelGGL((k_shade<X, UV>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
+                       ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
                        ctx->d_l[1], ctx->d_l[2], d, max_depth);
 }
 void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
@@ -830,22 +893,23 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     }
     auto mark = [&]() -> hipError_t { return profile ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (iters + 1) * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(iters + 1) * kShards * sizeof(uint32_t), st));
     const int g_all = grid_for(ctx, n);
     HIP_TRY(ctx, mark());
     if (realtime)
-        hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->d_keys, ctx->d_l[0],
-                           ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
+        hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->shape, ctx->d_keys,
+                           ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
     else
-        hipLaunchKernelGGL(k_raygen<false>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->d_keys, ctx->d_l[0],
-                           ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
+        hipLaunchKernelGGL(k_raygen<false>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->shape, ctx->d_keys,
+                           ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
     HIP_TRY(ctx, mark());
     for (uint32_t d = 0; d < iters; ++d) {
         const Queue &qi = ctx->q[d & 1];
         const Queue &qo = ctx->q[(d + 1) & 1];
         const int g_d = grid_for_bounce(ctx, n, d);
         ExtendArgs ea;
-        ea.count_ptr = ctx->d_counts + d;
+        ea.counts = ctx->d_counts + (size_t)d * kShards;
+        ea.sh = ctx->shape;
         ea.t_min = 0.001; // src/trace.rs:205
         ea.t_max = kF64Max;
         ea.keys = ctx->d_keys;
@@ -874,10 +938,13 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     ctx->stats.launches_shade += iters;
     ctx->stats.launches_resolve += 1;
     if (profile || read_counts) {
-        ctx->h_counts.resize(iters + 1);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts.data(), ctx->d_counts, (iters + 1) * sizeof(uint32_t),
-                                    hipMemcpyDeviceToHost, st));
+        ctx->h_shard_counts.resize((size_t)(iters + 1) * kShards);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_shard_counts.data(), ctx->d_counts,
+                                    ctx->h_shard_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        ctx->h_counts.assign(iters + 1, 0);
+        for (uint32_t d = 0; d <= iters; ++d)
+            for (uint32_t k = 0; k < kShards; ++k) ctx->h_counts[d] += ctx->h_shard_counts[(size_t)d * kShards + k];
         ctx->profile = ctx->h_counts;
         ctx->profile_n = n;
     }
@@ -1150,7 +1217,8 @@ static int intersect_common(pt_ctx *ctx, size_t n, double t_min, double t_max, u
     HIP_TRY(ctx, hipEventCreate(&e1));
     const int g = grid_for(ctx, n);
     ExtendArgs ea;
-    ea.count_ptr = ctx->d_counts;
+    ea.counts = ctx->d_counts;
+    ea.sh = QueueShape{1u, 0u, ctx->capacity}; // one shard: slot == ray index
     ea.t_min = t_min;
     ea.t_max = t_max;
     ea.keys = ctx->d_keys;

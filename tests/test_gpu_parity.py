@@ -191,7 +191,7 @@ def test_error_codes(gpu_ctx):
         fresh.render(8, 8, 0, 1)
     assert e.value.code == ptgpu.PT_ERR_INVALID_ARG
     with pytest.raises(ptgpu.PtError) as e:
-        fresh.intersect(np.zeros(5000, dtype=ptgpu.RAY_DTYPE))
+        fresh.intersect(np.zeros(20000, dtype=ptgpu.RAY_DTYPE))
     assert e.value.code == ptgpu.PT_ERR_TOO_LARGE
     fresh.close()
 
