@@ -140,12 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, uint6
             if (REALTIME) alive = !(pixel_skip_draw(pp.seed, pp.frame, pixel) < 0.8); // src/trace.rs:144
         }
         uint32_t local = row * kBlock + threadIdx.x;
-        if (REALTIME) {
-            local = compact_slot(alive, &counts[s_id], lds);
-        } else if (threadIdx.x == 0) {
-            const uint32_t left = n - j * kBlock;
-            atomicAdd(&counts[s_id], left < (uint32_t)kBlock ? left : (uint32_t)kBlock);
-        }
+        if (REALTIME) local = compact_slot(alive, &counts[s_id], lds);
         const uint32_t slot = s_id * sh.shard_cap + local;
         if (alive) {
             Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
@@ -171,6 +166,18 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, uint6
         if (pid < n) { // radiance accumulator of the path, also for skipped pixels
             lx[pid] = 0.0; ly[pid] = 0.0; lz[pid] = 0.0;
         }
+    }
+    if (!REALTIME && blockIdx.x == 0 && threadIdx.x < sh.shards) {
+        // offline: every path is generated, so shard k holds chunks k, k + shards, ... of the pass
+        const uint32_t k = threadIdx.x;
+        uint32_t fill = 0;
+        if (n_chunks > k) {
+            const uint32_t mine = (n_chunks - k + sh.shards - 1) >> sh.shift; // chunks of this shard
+            fill = mine * kBlock;
+            const uint32_t last = k + (mine - 1) * sh.shards;                // its last chunk
+            if (last == n_chunks - 1) fill -= n_chunks * kBlock - n;         // the pass's final chunk may be partial
+        }
+        counts[k] = fill;
     }
 }
 
@@ -405,7 +412,7 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
 }
 
 template <bool X, bool NEED_UV>
-__global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
+__global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
                                                   uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   const uint64_t *keys, double *lx, double *ly, double *lz,
                                                   uint32_t depth, uint32_t max_depth) {
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Queue qi, Queue qo, QueueShape
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
                 Rng g{keys[pid], qi.rn[i]};
-                const DevLeaf lf = sv.leaves[id & 0x0fffffff];
+                const DevLeaf &lf = sv.leaves[id & 0x0fffffff]; // fields are fetched where they are used
                 const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, hit_t[i], (id >> 28) & 7);
                 const D3 emissive = emitted(sv, lf, d, rec);
                 bool done = true;
