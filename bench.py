@@ -156,11 +156,13 @@ def main():
         dom_ms = max(ext_ms, shd_ms)
         dom_bytes_unit = b_ray if dominant == "extend" else b_shade
         achieved = (seg * dom_bytes_unit) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
+        # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(dominant)
+                traffic = json.load(open(prof))[dominant]["hbm_bytes_per_unit"] * seg / n_launch
             except Exception:
                 traffic = None
         result = {
