@@ -297,7 +297,7 @@ class Scene:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # at interpreter exit the module globals may already be gone
             lib.pt_scene_free(h)
             self._h = None
 
@@ -394,7 +394,7 @@ class Context:
         self.width = self.height = 0
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.pt_destroy(self._h)
             self._h = None
 

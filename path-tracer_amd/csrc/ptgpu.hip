@@ -314,7 +314,9 @@ __device__ __forceinline__ bool aabb_hit_fast(const double *b, D3 o, D3 inv, dou
     return ok && (tmax > tmin);
 }
 
-template <bool X, bool FRAMES, bool MEDIA>
+// LIST: the stream holds no BOX ops (see pt_scene_upload), so every lane wants every op and no per-lane index
+// is kept at all.
+template <bool X, bool FRAMES, bool MEDIA, bool LIST>
 __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, ExtendArgs a) {
     const bool count = a.counters != nullptr;
     unsigned long long my_nodes = 0, my_prims = 0;
@@ -341,14 +343,16 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
         int32_t c = -1;
         for (;;) {
             c += 1;
-            if (__ballot(cur == c) == 0ull) c = wave_min_i32(cur); // nobody wants the next op: jump ahead
-            c = __builtin_amdgcn_readfirstlane(c);
+            if (!LIST) {
+                if (__ballot(cur == c) == 0ull) c = wave_min_i32(cur); // nobody wants the next op: jump ahead
+                c = __builtin_amdgcn_readfirstlane(c);
+            }
             if (c >= end) break;
             const DevOp op = load_op_uniform(sv.ops + c); // uniform address: scalar loads into SGPRs
             const int32_t kword = __builtin_amdgcn_readfirstlane(op.kind);
             const int kind = kword & 0xff;
-            const bool mine = cur == c;
-            if (kind == OP_BOX) {
+            const bool mine = LIST ? valid : (cur == c);
+            if (!LIST && kind == OP_BOX) {
                 if (count && mine) ++my_nodes;
                 bool hit;
                 if constexpr (X) hit = aabb_hit(op.d, o, inv, a.t_min, closest);
@@ -703,6 +707,10 @@ struct pt_ctx {
     bool exact = false;            // PT_CFG_EXACT
     bool use_scan = false;         // wave-uniform extend for short op streams
     int scan_max_ops = 96;
+    bool scan_list = false;        // ... over the stream with its BOX ops removed
+    int list_max_leaves = 24;
+    void *d_ops_list = nullptr;
+    int32_t n_list_ops = 0;
     std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
     uint32_t profile_n = 0;        // its path count
 };
@@ -837,8 +845,14 @@ D3 hunit(D3 a) {
 
 template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
-    if (ctx->use_scan)
-        hipLaunchKernelGGL((k_extend_scan<X, FRAMES, MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+    if (ctx->use_scan && ctx->scan_list) {
+        SceneView v = ctx->view;
+        v.ops = (const DevOp *)ctx->d_ops_list;
+        v.n_traversal_ops = ctx->n_list_ops;
+        hipLaunchKernelGGL((k_extend_scan<X, FRAMES, MEDIA, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, v, a);
+    } else if (ctx->use_scan)
+        hipLaunchKernelGGL((k_extend_scan<X, FRAMES, MEDIA, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, q,
+                           ctx->view, a);
     else
         hipLaunchKernelGGL((k_extend<X, FRAMES, MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
 }
@@ -998,6 +1012,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     ctx->flags = cfg->flags;
     ctx->exact = (cfg->flags & PT_CFG_EXACT) != 0;
     if (const char *e = std::getenv("PTGPU_SCAN_MAX_OPS")) ctx->scan_max_ops = (int)std::strtol(e, nullptr, 10);
+    if (const char *e = std::getenv("PTGPU_LIST_MAX_LEAVES")) ctx->list_max_leaves = (int)std::strtol(e, nullptr, 10);
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;
     if (const char *e = std::getenv("PTGPU_PROFILE_PERIOD")) {
@@ -1025,6 +1040,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
+                    ctx->d_ops_list,
                     ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1084,6 +1100,34 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     for (int i = 0; i < scene->n_textures; ++i)
         if (scene->textures[i].kind == PT_T_IMAGE) ctx->need_uv = true;
     ctx->use_scan = f.n_traversal_ops <= ctx->scan_max_ops;
+    // In the wave-uniform traversal a primitive is tested as soon as ONE lane of the wave wants it, so a box test
+    // only pays when all 64 rays miss the box. For a handful of primitives that almost never happens, and the box
+    // tests cost more than the primitive tests they guard. Fast mode therefore scans the primitive ops alone, in the
+    // same order; exact mode keeps every box test, i.e. the reference's culling decisions, ray by ray.
+    ctx->scan_list = false;
+    if (ctx->use_scan && !ctx->exact) {
+        std::vector<DevOp> list;
+        for (int32_t k = 0; k < f.n_traversal_ops; ++k)
+            if (op_kind(f.ops[k].kind) != OP_BOX) list.push_back(f.ops[k]);
+        int prims = 0;
+        for (const DevOp &op : list) {
+            const int kind = op_kind(op.kind);
+            if (kind != OP_ENTER && kind != OP_EXIT) ++prims;
+        }
+        if (prims <= ctx->list_max_leaves) {
+            // MEDIUM ops keep pointing at their boundary ops in the full stream: rebase through an offset table
+            for (DevOp &op : list)
+                if (op_kind(op.kind) == OP_MEDIUM) op.skip = op.skip - f.n_traversal_ops + (int32_t)list.size() + 1;
+            ctx->n_list_ops = (int32_t)list.size();
+            DevOp sentinel;
+            std::memset(&sentinel, 0, sizeof(sentinel));
+            sentinel.kind = op_pack(OP_EXIT, 0, 0);
+            list.push_back(sentinel);
+            for (size_t k = (size_t)f.n_traversal_ops; k < f.ops.size(); ++k) list.push_back(f.ops[k]); // boundaries
+            if ((rc = upload(ctx, &ctx->d_ops_list, list.data(), list.size())) != PT_OK) return rc;
+            ctx->scan_list = true;
+        }
+    }
     ctx->profile.clear();
     ctx->profile_n = 0;
     ctx->have_scene = true;

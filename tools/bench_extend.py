@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Extend-only benchmark and parity on the fixed ray batches: per scene, 2^20 primary camera rays (sample 0 of a
+1024x1024 image) and up to 2^20 secondary rays (cosine-sampled about the primary hit normals), t_min = 0.001.
+Reports Mrays/s of the extend kernel with the rays resident in HBM (pt_intersect_device), the CPU oracle's
+Mrays/s on one core, and id / t agreement between the two on the whole batch.
+
+usage: bench_extend.py [scene ...]     (default: cornell_box random_scene final_book_two sphere_cloud)
+"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pt = importlib.import_module("path-tracer_amd")
+import oracle_binding as ob
+
+scenes = sys.argv[1:] or ["cornell_box", "random_scene", "final_book_two", "sphere_cloud"]
+W = H = 1024
+for name in scenes:
+    scene = pt.Scene.named(name, 1.0, param=1000000 if name == "sphere_cloud" else 0)
+    info = scene.flatten_info()
+    ctx = pt.Context(device=0, max_paths_in_flight=1 << 20)
+    ctx.upload(scene)
+    pix = np.arange(W * H, dtype=np.uint64)
+    primary = ob.camera_rays(scene.camera, W, H, pix, np.zeros(W * H, dtype=np.uint32))
+    t0 = time.perf_counter()
+    ref_p, st_p = ob.intersect(scene.desc(), primary, medium_seed=5)
+    cpu_s = time.perf_counter() - t0
+    secondary, valid = ob.secondary_rays(ref_p, primary)
+    secondary = secondary[valid]
+    for label, rays, ref in (("primary", primary, ref_p), ("secondary", secondary, None)):
+        if ref is None:
+            t0 = time.perf_counter()
+            ref, st = ob.intersect(scene.desc(), rays, medium_seed=5)
+            cpu = time.perf_counter() - t0
+        else:
+            st, cpu = st_p, cpu_s
+        n = len(rays)
+        soa = np.concatenate([rays["origin"][:, k] for k in range(3)] + [rays["direction"][:, k] for k in range(3)] + [rays["time"]])
+        d_soa = torch.from_numpy(np.ascontiguousarray(soa)).cuda()
+        ctx.intersect_device(d_soa.data_ptr(), n, medium_seed=5, repeats=3)
+        ms = ctx.intersect_device(d_soa.data_ptr(), n, medium_seed=5, repeats=20)
+        got = ctx.intersect(rays, medium_seed=5)
+        same = got["prim"] == ref["prim"]
+        both = same & (ref["prim"] >= 0)
+        rel = np.abs(got["t"][both] - ref["t"][both]) / np.maximum(np.abs(ref["t"][both]), 1e-300)
+        V, P = st.node_visits / n, st.prim_tests / n
+        print(json.dumps({
+            "scene": name, "batch": label, "rays": n, "ops": info["n_ops"], "gpu_ms": ms, "gpu_Mrays_s": n / ms / 1e3,
+            "cpu_1core_Mrays_s": n / cpu / 1e6, "id_agreement": float(same.mean()), "max_rel_t_err": float(rel.max()) if rel.size else 0.0,
+            "hit_fraction": float((ref["prim"] >= 0).mean()), "V": V, "P": P,
+            "algorithmic_GBs": n * (36 + 32 * (V + P)) / (ms * 1e-3) / 1e9,
+        }), flush=True)
+    ctx.close()
