@@ -402,6 +402,28 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
     }
 }
 
+// Closest hit over a box-free op list (see pt_scene_upload): every lane of the wave tests every primitive, in
+// stream order, with op records coming through the scalar cache. Must be called by all 64 lanes of a wave.
+template <bool X, bool MEDIA>
+__device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *ops, int32_t n_ops, D3 o, D3 d, double time,
+                                            uint64_t pkey, uint32_t depth, double t_min, double t_max, double &closest,
+                                            int32_t &best) {
+    const D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+    closest = t_max;
+    best = -1;
+    for (int32_t c = 0; c < n_ops; ++c) {
+        const DevOp op = load_op_uniform(ops + c);
+        const int kind = __builtin_amdgcn_readfirstlane(op.kind) & 0xff;
+        double t = 0.0;
+        int sub = 0;
+        bool hit;
+        if (MEDIA && kind == OP_MEDIUM) hit = medium_hit<X>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
+        else hit = prim_hit<X>(sv, op, o, d, inv, time, t_min, closest, t, sub);
+        closest = hit ? t : closest;
+        best = hit ? (op.leaf | (sub << 28)) : best;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // shade + compaction
 // ------------------------------------------------------------------------------------------------------------
@@ -415,7 +437,11 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
     }
 }
 
-template <bool X, bool NEED_UV>
+// FUSE = 0: hits come from the extend kernel through hit_t / hit_id.
+// FUSE = 1 / 2: the scene is a short box-free op list (2: with media); the ray is traced right here before it is
+// shaded, so the extend launch, its re-read of the ray and the hit round trip through HBM disappear. The op list is
+// passed in sv.ops / sv.n_traversal_ops.
+template <bool X, bool NEED_UV, int FUSE>
 __global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
                                                   uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   const uint64_t *keys, double *lx, double *ly, double *lz,
@@ -434,20 +460,36 @@ __global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo,
         D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
         double time = 0.0;
         uint32_t pid = 0, rn = 0;
+        D3 o, d;
+        double ht = 0.0;
+        int32_t id = -1;
+        if (FUSE) { // whole waves walk the op list together; lanes past the end trace the shard's first ray
+            const uint32_t il = (i < n) ? i : s_id * sh.shard_cap;
+            o = d3(qi.ox[il], qi.oy[il], qi.oz[il]);
+            d = d3(qi.dx[il], qi.dy[il], qi.dz[il]);
+            time = qi.tm[il];
+            pid = qi.pid[il];
+            uint64_t pkey = 0;
+            if (FUSE == 2) pkey = keys[pid];
+            extend_list<X, FUSE == 2>(sv, sv.ops, sv.n_traversal_ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
+        }
         if (i < n) {
-            const D3 o = d3(qi.ox[i], qi.oy[i], qi.oz[i]);
-            const D3 d = d3(qi.dx[i], qi.dy[i], qi.dz[i]);
-            time = qi.tm[i];
+            if (!FUSE) {
+                o = d3(qi.ox[i], qi.oy[i], qi.oz[i]);
+                d = d3(qi.dx[i], qi.dy[i], qi.dz[i]);
+                time = qi.tm[i];
+                pid = qi.pid[i];
+                id = hit_id[i];
+                ht = hit_t[i];
+            }
             const D3 beta = d3(qi.bx[i], qi.by[i], qi.bz[i]);
-            pid = qi.pid[i];
-            const int32_t id = hit_id[i];
             if (id < 0) {
                 // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
                 Rng g{keys[pid], qi.rn[i]};
                 const DevLeaf &lf = sv.leaves[id & 0x0fffffff]; // fields are fetched where they are used
-                const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, hit_t[i], (id >> 28) & 7);
+                const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, ht, (id >> 28) & 7);
                 const D3 emissive = emitted(sv, lf, d, rec);
                 bool done = true;
                 if (depth < max_depth) {
@@ -708,6 +750,7 @@ struct pt_ctx {
     bool use_scan = false;         // wave-uniform extend for short op streams
     int scan_max_ops = 96;
     bool scan_list = false;        // ... over the stream with its BOX ops removed
+    bool fuse = true;              // trace inside the shade kernel when scan_list applies (PTGPU_FUSE=0 disables)
     int list_max_leaves = 24;
     void *d_ops_list = nullptr;
     int32_t n_list_ops = 0;
@@ -867,19 +910,31 @@ void launch_extend(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
     if (ctx->exact) launch_extend_x<true>(ctx, grid, q, a);
     else launch_extend_x<false>(ctx, grid, q, a);
 }
-template <bool X, bool UV>
-void launch_shade_xu(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
-    hipLaunchKernelGGL((k_shade<X, UV>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
-                       ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, ctx->view, ctx->d_hit_t, ctx->d_hit_id, ctx->d_keys, ctx->d_l[0],
-                       ctx->d_l[1], ctx->d_l[2], d, max_depth);
+template <bool X, bool UV, int FUSE>
+void launch_shade_xuf(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
+    SceneView v = ctx->view;
+    if (FUSE) {
+        v.ops = (const DevOp *)ctx->d_ops_list;
+        v.n_traversal_ops = ctx->n_list_ops;
+    }
+    hipLaunchKernelGGL((k_shade<X, UV, FUSE>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
+                       ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, v, ctx->d_hit_t,
+                       ctx->d_hit_id, ctx->d_keys, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth);
 }
-void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
+// fused = trace inside the shade kernel (fast mode, box-free list, no transformed subtrees)
+void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth, bool fused) {
     if (ctx->exact) {
-        if (ctx->need_uv) launch_shade_xu<true, true>(ctx, grid, qi, qo, d, max_depth);
-        else launch_shade_xu<true, false>(ctx, grid, qi, qo, d, max_depth);
+        if (ctx->need_uv) launch_shade_xuf<true, true, 0>(ctx, grid, qi, qo, d, max_depth);
+        else launch_shade_xuf<true, false, 0>(ctx, grid, qi, qo, d, max_depth);
+    } else if (!fused) {
+        if (ctx->need_uv) launch_shade_xuf<false, true, 0>(ctx, grid, qi, qo, d, max_depth);
+        else launch_shade_xuf<false, false, 0>(ctx, grid, qi, qo, d, max_depth);
+    } else if (ctx->view.has_medium) {
+        if (ctx->need_uv) launch_shade_xuf<false, true, 2>(ctx, grid, qi, qo, d, max_depth);
+        else launch_shade_xuf<false, false, 2>(ctx, grid, qi, qo, d, max_depth);
     } else {
-        if (ctx->need_uv) launch_shade_xu<false, true>(ctx, grid, qi, qo, d, max_depth);
-        else launch_shade_xu<false, false>(ctx, grid, qi, qo, d, max_depth);
+        if (ctx->need_uv) launch_shade_xuf<false, true, 1>(ctx, grid, qi, qo, d, max_depth);
+        else launch_shade_xuf<false, false, 1>(ctx, grid, qi, qo, d, max_depth);
     }
 }
 
@@ -900,6 +955,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const bool realtime = pp.mode == PT_MODE_REALTIME;
     const bool profile = (ctx->flags & PT_CFG_PROFILE_STAGES) && (ctx->pass_counter % ctx->profile_period == 0);
     const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
+    const bool fused = ctx->fuse && ctx->scan_list && !ctx->exact && !count && !ctx->view.has_frames;
     ctx->pass_counter++;
     hipStream_t st = ctx->stream;
     const uint32_t iters = pp.max_depth + 1;
@@ -941,10 +997,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         ea.hit_id = ctx->d_hit_id;
         ea.counters = count ? ctx->d_trav : nullptr;
         HIP_TRY(ctx, mark());
-        launch_extend(ctx, g_d, qi, ea);
+        if (!fused) launch_extend(ctx, g_d, qi, ea);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
-        launch_shade(ctx, g_d, qi, qo, d, pp.max_depth);
+        launch_shade(ctx, g_d, qi, qo, d, pp.max_depth, fused);
         HIP_TRY(ctx, mark());
     }
     HIP_TRY(ctx, mark());
@@ -955,7 +1011,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, hipGetLastError());
     ctx->stats.paths += n;
     ctx->stats.launches_raygen += 1;
-    ctx->stats.launches_extend += iters;
+    ctx->stats.launches_extend += fused ? 0 : iters;
     ctx->stats.launches_shade += iters;
     ctx->stats.launches_resolve += 1;
     if (profile || read_counts) {
@@ -1013,6 +1069,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     ctx->exact = (cfg->flags & PT_CFG_EXACT) != 0;
     if (const char *e = std::getenv("PTGPU_SCAN_MAX_OPS")) ctx->scan_max_ops = (int)std::strtol(e, nullptr, 10);
     if (const char *e = std::getenv("PTGPU_LIST_MAX_LEAVES")) ctx->list_max_leaves = (int)std::strtol(e, nullptr, 10);
+    if (const char *e = std::getenv("PTGPU_FUSE")) ctx->fuse = std::strtol(e, nullptr, 10) != 0;
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;
     if (const char *e = std::getenv("PTGPU_PROFILE_PERIOD")) {
