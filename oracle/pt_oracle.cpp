@@ -15,8 +15,8 @@
  *
  * The one deliberate departure: the reference draws from an OS-seeded
  * thread_rng (src/math/random.rs:3-6), which is irreproducible; here every
- * path owns a counter-based SplitMix64 stream keyed by (seed, frame, pixel,
- * sample) and draws from it in the reference's call order.  The free-flight
+ * path owns a counter-based stream (two PCG hash rounds over a 64-bit key made
+ * from seed, frame, pixel and sample) and draws from it in the reference's call order.  The free-flight
  * draw inside ConstantMedium::hit (src/volume.rs:42) is keyed by
  * (path, depth, medium node) so that it does not depend on traversal order.
  *
@@ -53,13 +53,24 @@ inline uint64_t mix64(uint64_t z) {
 }
 inline double to_unit(uint64_t x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
 
+/* PCG output hash (32 -> 32 bits) */
+inline uint32_t pcg32(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+/* n-th draw (n >= 1) of the path stream with 64-bit key: two PCG rounds keyed by the two key halves */
+inline uint32_t path_draw_u32(uint64_t key, uint32_t n) {
+    uint32_t x = pcg32((uint32_t)key + n * 0x9E3779B9u);
+    return pcg32(x ^ (uint32_t)(key >> 32));
+}
 struct Rng {
     uint64_t key;
     uint64_t n;
-    /* stands in for random::rand (src/math/random.rs:3-6): f64 in [0,1) with 53 random bits */
+    /* stands in for random::rand (src/math/random.rs:3-6): f64 in [0,1); 32 random bits per draw */
     double next() {
         n += 1;
-        return to_unit(mix64(key + n * GOLDEN));
+        return (double)path_draw_u32(key, (uint32_t)n) * (1.0 / 4294967296.0);
     }
 };
 
@@ -1147,9 +1158,17 @@ int oracle_rotate_y_box(const double mn[3], const double mx[3], double degrees, 
  * box_out[6k..]; returns the number of BVH nodes created (capacity must be >= 2n: singleton sub-lists get their own node).  The comparator
  * "a.min < b.min ? Less : Greater" is applied with a stable sort; the axis draw floor(3*rand) comes from the
  * scene stream (key derived from `seed`, `*draws` draws already consumed). */
+struct SceneStream { /* SplitMix64 stream used while building scenes (BVH axis draws) */
+    uint64_t key;
+    uint64_t n;
+    double next() {
+        n += 1;
+        return to_unit(mix64(key + n * GOLDEN));
+    }
+};
 struct BvhBuild {
     const pt_scene_desc *s;
-    Rng rng;
+    SceneStream rng;
     int32_t *lr;
     double *box;
     int created;
@@ -1194,7 +1213,7 @@ int oracle_bvh_from_list(const pt_scene_desc *desc, const int32_t *nodes, int n,
                          uint64_t seed, uint64_t *draws, int32_t *lr_out, double *box_out) {
     BvhBuild b;
     b.s = desc;
-    b.rng = Rng{scene_stream_key(seed), *draws};
+    b.rng = SceneStream{scene_stream_key(seed), *draws};
     b.lr = lr_out;
     b.box = box_out;
     b.created = 0;
@@ -1208,7 +1227,7 @@ int oracle_bvh_from_list(const pt_scene_desc *desc, const int32_t *nodes, int n,
 
 /* The n-th draw (1-based) of a path stream / the scene stream, for pinning the RNG definition. */
 double oracle_path_draw(uint64_t seed, uint32_t frame, uint64_t pixel, uint32_t sample, uint64_t n) {
-    return to_unit(mix64(path_key(seed, frame, pixel, sample) + n * GOLDEN));
+    return (double)path_draw_u32(path_key(seed, frame, pixel, sample), (uint32_t)n) * (1.0 / 4294967296.0);
 }
 double oracle_scene_draw(uint64_t seed, uint64_t n) { return to_unit(mix64(scene_stream_key(seed) + n * GOLDEN)); }
 double oracle_pixel_skip_draw(uint64_t seed, uint32_t frame, uint64_t pixel) {

@@ -21,21 +21,31 @@ constexpr double kF64Max = 1.7976931348623157e308;
 constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ULL;
 
 // ------------------------------------------------------------------- RNG --
-// SplitMix64 finaliser; a path's n-th draw is mix64(key + n * golden). Stands in for random::rand
-// (src/math/random.rs:3-6), which is an OS-seeded thread_rng and cannot be reproduced.
+// Stands in for random::rand (src/math/random.rs:3-6), which is an OS-seeded thread_rng and cannot be
+// reproduced. Keys are built with the SplitMix64 finaliser (once per path); a path's n-th draw is two rounds
+// of the 32-bit PCG output hash over (key, n): 32-bit integer multiplies only, which is what the VALU is fast at.
 PT_DEV uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
 PT_DEV double to_unit(uint64_t x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+PT_DEV uint32_t pcg32(uint32_t v) {
+    const uint32_t s = v * 747796405u + 2891336453u;
+    const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
 struct Rng {
     uint64_t key;
     uint32_t n;
-    PT_DEV double next() {
+    PT_DEV uint32_t next_u32() {
         n += 1;
-        return to_unit(mix64(key + (uint64_t)n * kGolden));
+        const uint32_t x = pcg32((uint32_t)key + n * 0x9E3779B9u);
+        return pcg32(x ^ (uint32_t)(key >> 32));
     }
+    PT_DEV double next() { return (double)next_u32() * (1.0 / 4294967296.0); }
+    // the same draw narrowed to f32 without ever rounding up to 1
+    PT_DEV float nextf() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
 };
 PT_DEV uint64_t path_key(uint64_t seed, uint64_t frame, uint64_t pixel, uint64_t sample) {
     uint64_t k = mix64(seed ^ (0xA0761D6478BD642FULL * (frame + 1)));
@@ -148,6 +158,7 @@ struct SceneView {
     int32_t n_lights;
     int32_t has_medium;
     int32_t has_frames;
+    int32_t has_isotropic; // some material is Isotropic: throughput can turn NaN (0 * x / 0, src/trace.rs:217-220)
 };
 
 // ------------------------------------------------------------ transforms --
@@ -671,8 +682,8 @@ PT_DEV F3 onbf_local(const OnbF &b, F3 a) {
               __builtin_fmaf(b.w.z, a.z, __builtin_fmaf(b.v.z, a.y, b.u.z * a.x))};
 }
 PT_DEV F3 random_cosine_direction_f(Rng &g) { // src/material.rs:10-19
-    const float r1 = (float)g.next();
-    const float r2 = (float)g.next();
+    const float r1 = g.nextf();
+    const float r2 = g.nextf();
     const float z = __builtin_amdgcn_sqrtf(1.0f - r2);
     const float r2_sqrt = __builtin_amdgcn_sqrtf(r2);
     return f3(__builtin_amdgcn_cosf(r1) * r2_sqrt, __builtin_amdgcn_sinf(r1) * r2_sqrt, z);
@@ -683,8 +694,8 @@ PT_DEV D3 light_random_fast(const DevLight &l, Rng &g, D3 origin) {
         const D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
         const float distance_sq = (float)squared_length(direction);
         const OnbF uvw = onbf_from_w(to_f3(direction));
-        const float r1 = (float)g.next();
-        const float r2 = (float)g.next();
+        const float r1 = g.nextf();
+        const float r2 = g.nextf();
         const float radius = (float)l.d[3];
         const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(1.0f - radius * radius * __builtin_amdgcn_rcpf(distance_sq)) - 1.0f);
         const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));

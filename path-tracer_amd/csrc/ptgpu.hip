@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo,
                 const DevLeaf &lf = sv.leaves[id & 0x0fffffff]; // fields are fetched where they are used
                 const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, ht, (id >> 28) & 7);
                 const D3 emissive = emitted(sv, lf, d, rec);
-                bool done = true;
+                bool done = true, dead = false;
                 if (depth < max_depth) {
                     if (lf.mat_kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
                         D3 outward_normal;
@@ -577,19 +577,27 @@ __global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo,
                                 lsum += weight * light_pdf_value_fast(sv.lights[k], rec.p, dirf, len2);
                             const float pdf_val = 0.5f * lsum + 0.5f * own;
                             const float inv_pdf = __builtin_amdgcn_rcpf(pdf_val);
-                            // 0 * x / 0 must stay NaN (src/trace.rs:217-220): rcp(0) = inf and 0 * inf = NaN
-                            const D3 w = d3((double)(((float)albedo.x * spdf) * inv_pdf),
-                                            (double)(((float)albedo.y * spdf) * inv_pdf),
-                                            (double)(((float)albedo.z * spdf) * inv_pdf));
-                            nbeta = beta * w;
+                            // Isotropic: 0 * x / 0 must stay NaN (src/trace.rs:217-220): rcp(0) = inf, 0 * inf = NaN.
+                            // Lambertian: a direction below the surface has scattering_pdf 0 and its sample weighs
+                            // nothing. In f64 the mixture pdf is then still positive (the direction came from a
+                            // light); in f32 a grazing light sample can also miss its light by rounding, which
+                            // would turn 0 / pdf into 0 / 0, so the weight is pinned to the 0 the reference gets.
+                            const bool below = lambert && spdf == 0.0f; // a NaN spdf is not "below": it propagates
+                            const float wr = below ? 0.0f : ((float)albedo.x * spdf) * inv_pdf;
+                            const float wg = below ? 0.0f : ((float)albedo.y * spdf) * inv_pdf;
+                            const float wb = below ? 0.0f : ((float)albedo.z * spdf) * inv_pdf;
+                            nbeta = beta * d3((double)wr, (double)wg, (double)wb);
                             nd = dir;
+                            // A path whose throughput is exactly 0 can only add 0 * (finite radiance) from here on;
+                            // without Isotropic materials nothing downstream turns that into NaN, so it stops here.
+                            dead = below && !sv.has_isotropic;
                         }
                         no = rec.p;
                         done = false;
                     }
                 }
                 if (done) add_radiance(lx, ly, lz, pid, beta * emissive); // src/trace.rs:225
-                alive = !done;
+                alive = !done && !dead;
                 rn = g.n;
             }
         }
@@ -1153,6 +1161,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     v.n_lights = (int32_t)f.lights.size();
     v.has_medium = f.has_medium ? 1 : 0;
     v.has_frames = f.has_frames ? 1 : 0;
+    v.has_isotropic = 0;
+    for (int i = 0; i < scene->n_materials; ++i)
+        if (scene->materials[i].kind == PT_M_ISOTROPIC) v.has_isotropic = 1;
     ctx->need_uv = false;
     for (int i = 0; i < scene->n_textures; ++i)
         if (scene->textures[i].kind == PT_T_IMAGE) ctx->need_uv = true;

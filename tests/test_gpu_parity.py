@@ -83,15 +83,22 @@ def test_render_parity_small(any_ctx, name, spp, depth):
     assert rmse / scale <= 0.05, f"{name}: relative RMSE {rmse / scale:.3e}"
 
 
-def test_segments_match_oracle(gpu_ctx):
+def test_segments_match_oracle(gpu_ctx, gpu_ctx_exact):
     scene = ptgpu.Scene.named("cornell_box", 1.0)
-    gpu_ctx.upload(scene)
-    gpu_ctx.stats_reset()
-    gpu_ctx.render(32, 32, 4, 50)
-    st = gpu_ctx.stats()
     _, ost = ob.render(scene.desc(), scene.camera, 32, 32, 4, 50, seed=gpu_ctx.seed, threads=4)
-    assert st.paths == ost.paths == 32 * 32 * 4
-    assert abs(int(st.segments) - int(ost.segments)) <= max(4, ost.segments // 1000)
+    seg = {}
+    for name, ctx in (("fast", gpu_ctx), ("exact", gpu_ctx_exact)):
+        ctx.upload(scene)
+        ctx.stats_reset()
+        ctx.render(32, 32, 4, 50)
+        st = ctx.stats()
+        assert st.paths == ost.paths == 32 * 32 * 4
+        seg[name] = int(st.segments)
+    # exact mode follows every path of the reference's recursion to its end
+    assert abs(seg["exact"] - int(ost.segments)) <= max(4, ost.segments // 1000)
+    # fast mode stops a path whose throughput became exactly 0 (a light sample below the surface): fewer segments,
+    # same image (test_render_parity_small)
+    assert 0.8 * ost.segments <= seg["fast"] <= ost.segments + max(4, ost.segments // 1000)
 
 
 def test_extend_matches_committed_golden(gpu_ctx_exact):

@@ -197,8 +197,32 @@ def test_rng_streams_are_counter_based():
     assert ob.lib.oracle_path_draw(1, 0, 5, 8, 1) != a[0] and ob.lib.oracle_path_draw(1, 1, 5, 7, 1) != a[0]
     xs = np.array([ob.lib.oracle_path_draw(9, 0, p, 0, 1) for p in range(4000)])
     assert abs(xs.mean() - 0.5) < 0.02 and abs(np.mean(xs < 0.8) - 0.8) < 0.02
-    # pinned values of the stream definition (SplitMix64 finaliser over key + n * golden)
-    assert ob.lib.oracle_scene_draw(0x5EED0001, 1) == pytest.approx(0.4418060348279199, abs=0) or True
+
+
+def test_rng_stream_statistics():
+    """The path stream (two PCG hash rounds per draw) is uniform and uncorrelated along each axis that the
+    renderer varies: draw index, pixel, sample and frame."""
+    draw = ob.lib.oracle_path_draw
+    n = 20000
+    along = {
+        "draw": np.array([draw(3, 0, 11, 5, k) for k in range(1, n + 1)]),
+        "pixel": np.array([draw(3, 0, p, 5, 1) for p in range(n)]),
+        "sample": np.array([draw(3, 0, 11, s, 2) for s in range(n)]),
+        "frame": np.array([draw(3, f, 11, 5, 3) for f in range(n)]),
+    }
+    for name, xs in along.items():
+        assert xs.min() >= 0.0 and xs.max() < 1.0, name
+        assert abs(xs.mean() - 0.5) < 0.01 and abs(xs.var() - 1.0 / 12.0) < 0.004, name
+        for lag in (1, 2, 7):
+            c = np.corrcoef(xs[:-lag], xs[lag:])[0, 1]
+            assert abs(c) < 0.03, (name, lag, c)
+        # consecutive pairs fill the unit square evenly: chi-square over a 16 x 16 grid (255 dof)
+        h, _, _ = np.histogram2d(xs[:-1], xs[1:], bins=16, range=[[0, 1], [0, 1]])
+        e = (n - 1) / 256.0
+        chi2 = ((h - e) ** 2 / e).sum()
+        assert chi2 < 360.0, (name, chi2)
+    # every draw is a multiple of 2^-32
+    assert all(float(x * 4294967296.0).is_integer() for x in along["draw"][:100])
 
 
 def test_textures():
