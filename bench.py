@@ -31,10 +31,12 @@ def algorithmic_bytes(V, P):
     """Per-unit HBM bytes of the compact layout the roofline is priced on: a ray is 28 B (f32 origin, direction,
     time), a hit 8 B, a BVH node / primitive / material record 32 B, a queue entry 48 B (ray + pixel + throughput).
     extend: read ray, write hit, fetch V nodes + P primitives. shade: read queue entry + hit, fetch primitive +
-    material, write the next queue entry."""
+    material, write the next queue entry. The fused trace+shade kernel does both on one queue entry and never
+    writes or re-reads the hit."""
     b_ray = 28 + 8 + 32.0 * (V + P)
     b_shade = 48 + 8 + 32 + 32 + 48
-    return b_ray, b_shade
+    b_fused = 48 + 32.0 * (V + P) + 32 + 32 + 48
+    return b_ray, b_shade, b_fused
 
 
 def cpu_baseline(scene, width, height, max_depth, target_seconds=12.0):
@@ -148,13 +150,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, W, H, args.max_depth)
             V, P = cpu["V"], cpu["P"]
-        b_ray, b_shade = algorithmic_bytes(V, P)
+        b_ray, b_shade, b_fused = algorithmic_bytes(V, P)
         n_launch = max(int(st.profiled_bounce_launches), 1)
         seg = float(st.profiled_segments)
         ext_ms, shd_ms = st.ms_extend, st.ms_shade
-        dominant = "extend" if ext_ms >= shd_ms else "shade"
-        dom_ms = max(ext_ms, shd_ms)
-        dom_bytes_unit = b_ray if dominant == "extend" else b_shade
+        # no extend launches: the scene is a short primitive list and every bounce is one fused trace+shade launch
+        fused = int(st.launches_extend) == 0
+        if fused:
+            dominant, dom_ms, dom_bytes_unit = "shade_fused", shd_ms, b_fused
+        else:
+            dominant = "extend" if ext_ms >= shd_ms else "shade"
+            dom_ms = max(ext_ms, shd_ms)
+            dom_bytes_unit = b_ray if dominant == "extend" else b_shade
         achieved = (seg * dom_bytes_unit) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
         # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
@@ -187,7 +194,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"k_{dominant}",
+                "kernel": {"extend": "k_extend_scan", "shade": "k_shade", "shade_fused": "k_shade<FUSE=1>"}[dominant],
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -201,11 +208,12 @@ def main():
                 "P": P,
                 "profiled_launches": n_launch,
                 "other": {
-                    "extend_ms_total": ext_ms,
+                    "fused_trace_shade": fused,
+                    "extend_ms_total": None if fused else ext_ms,
                     "shade_ms_total": shd_ms,
                     "raygen_ms_total": st.ms_raygen,
                     "resolve_ms_total": st.ms_resolve,
-                    "extend_Mrays_s": seg / (ext_ms * 1e-3) / 1e6 if ext_ms > 0 else None,
+                    "extend_Mrays_s": seg / (ext_ms * 1e-3) / 1e6 if (ext_ms > 0 and not fused) else None,
                     "shade_Msegments_s": seg / (shd_ms * 1e-3) / 1e6 if shd_ms > 0 else None,
                 },
             },

@@ -155,6 +155,7 @@ struct SceneView {
     const uint8_t *texels;
     const pt_perlin *perlin;
     int32_t n_traversal_ops;
+    int32_t n_leaves;
     int32_t n_lights;
     int32_t has_medium;
     int32_t has_frames;

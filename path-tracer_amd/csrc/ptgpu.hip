@@ -27,6 +27,9 @@ using namespace ptdev;
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4 // waves per SIMD the fast shade kernels are compiled for (512 / this = VGPR budget)
+#endif
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kDefaultPathsInFlight = 1u << 22;
 constexpr int kMaxDepthSlots = 1024; // bounce slots of counts[]; max_depth is capped at kMaxDepthSlots - 2
@@ -441,12 +444,30 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
 // FUSE = 1 / 2: the scene is a short box-free op list (2: with media); the ray is traced right here before it is
 // shaded, so the extend launch, its re-read of the ray and the hit round trip through HBM disappear. The op list is
 // passed in sv.ops / sv.n_traversal_ops.
+// A leaf record padded to 200 B: with a stride of 50 dwords the same field of different leaves spreads over 16 LDS
+// banks instead of 2.
+struct LdsLeaf {
+    DevLeaf l;
+    double pad;
+};
+constexpr int kLdsLeaves = 32; // the fused kernels keep the whole leaf table in LDS
+
 template <bool X, bool NEED_UV, int FUSE>
-__global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
+__global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
                                                   uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   const uint64_t *keys, double *lx, double *ly, double *lz,
                                                   uint32_t depth, uint32_t max_depth) {
     __shared__ uint32_t lds[kWavesPerBlock + 1];
+    __shared__ LdsLeaf s_leaves[FUSE ? kLdsLeaves : 1];
+    if constexpr (FUSE != 0) {
+        // Shading gathers ~100 B of its leaf per lane through a chain of dependent loads (kind -> geometry ->
+        // material); from LDS each link costs tens of cycles instead of an L1/L2 round trip.
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&s_leaves[k / kWords].l)[k % kWords] = src[k];
+        __syncthreads();
+    }
     const uint32_t n_virtual = ((max_shard_count(n_in, sh.shards) + kBlock - 1) / kBlock) << sh.shift;
     for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
         const uint32_t s_id = v & (sh.shards - 1);
@@ -488,7 +509,10 @@ __global__ __launch_bounds__(kBlock, X ? 1 : 4) void k_shade(Queue qi, Queue qo,
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
                 Rng g{keys[pid], qi.rn[i]};
-                const DevLeaf &lf = sv.leaves[id & 0x0fffffff]; // fields are fetched where they are used
+                const DevLeaf *lfp; // fields are fetched where they are used
+                if constexpr (FUSE != 0) lfp = &s_leaves[id & 0x0fffffff].l;
+                else lfp = &sv.leaves[id & 0x0fffffff];
+                const DevLeaf &lf = *lfp;
                 const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, ht, (id >> 28) & 7);
                 const D3 emissive = emitted(sv, lf, d, rec);
                 bool done = true, dead = false;
@@ -1159,6 +1183,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     v.perlin = (const pt_perlin *)ctx->d_perlin;
     v.n_traversal_ops = f.n_traversal_ops;
     v.n_lights = (int32_t)f.lights.size();
+    v.n_leaves = (int32_t)f.leaves.size();
     v.has_medium = f.has_medium ? 1 : 0;
     v.has_frames = f.has_frames ? 1 : 0;
     v.has_isotropic = 0;
@@ -1182,7 +1207,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
             const int kind = op_kind(op.kind);
             if (kind != OP_ENTER && kind != OP_EXIT) ++prims;
         }
-        if (prims <= ctx->list_max_leaves) {
+        if (prims <= ctx->list_max_leaves && (int)f.leaves.size() <= kLdsLeaves) {
             // MEDIUM ops keep pointing at their boundary ops in the full stream: rebase through an offset table
             for (DevOp &op : list)
                 if (op_kind(op.kind) == OP_MEDIUM) op.skip = op.skip - f.n_traversal_ops + (int32_t)list.size() + 1;
