@@ -23,7 +23,8 @@ enum OpKind : int32_t {
     OP_MSPHERE = 4, // d = center0 xyz, radius, time0, time_range ; leaf.e = center_range xyz
     OP_MEDIUM = 5,  // d[0] = density ; skip = index of the boundary op (stored after the traversal ops)
     OP_ENTER = 6,   // enter a transformed subtree: apply chain [chain_start, +chain_count) to the current ray
-    OP_EXIT = 7     // leave it: current ray = world ray transformed by chain [chain_start, +chain_count)
+    OP_EXIT = 7,    // leave it: current ray = world ray transformed by chain [chain_start, +chain_count)
+    OP_XFORM = 8    // fused list streams only: d = one DevXform step (tx ty tz s c sign) for the next primitive op
 };
 
 struct DevOp { // 64 bytes

@@ -336,6 +336,26 @@ template <bool X> PT_DEV D3 moving_center(const double *pd, const double *e, dou
 // One primitive op against a ray that is already in the op's frame; applies the op's own chain first.
 // `inv` is 1 / d of the frame ray (fast mode only; recomputed here if the op's chain rotates the ray).
 // `sub` is the near/far root for spheres and the face for boxes.
+// The test itself, for a ray that is already in the primitive's own frame.
+template <bool X>
+PT_DEV bool prim_hit_framed(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, double time, double t_min,
+                            double t_max, double &t_out, int &sub) {
+    const int kind = op.kind & 0xff;
+    sub = 0;
+    switch (kind) {
+    case OP_SPHERE:
+        return sphere_t<X>(d3(op.d[0], op.d[1], op.d[2]), op.d[3], o, d, t_min, t_max, t_out, sub);
+    case OP_MSPHERE:
+        return sphere_t<X>(moving_center<X>(op.d, sv.leaves[op.leaf].e, time), op.d[3], o, d, t_min, t_max, t_out, sub);
+    case OP_RECT:
+        return rect_t<X>(op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], (op.kind >> 8) & 3, o, d, inv, t_min, t_max,
+                         t_out);
+    case OP_BOXPRIM:
+        return box_t<X>(op.d, o, d, inv, t_min, t_max, t_out, sub);
+    default:
+        return false;
+    }
+}
 template <bool X>
 PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, double time, double t_min,
                      double t_max, double &t_out, int &sub) {

@@ -48,11 +48,33 @@ struct QueueShape {
 // ------------------------------------------------------------------------------------------------------------
 // Path-state queues (structure of arrays, one entry per in-flight ray)
 // ------------------------------------------------------------------------------------------------------------
+// An entry is 88 B: the ray (src/math/ray.rs:3-7), the path throughput, the path id within the pass and the number
+// of RNG draws consumed so far. Entries are stored in tiles of 64 (one wavefront): inside a tile every field is a
+// contiguous run of 64 values, so a wave's access to one field is one fully coalesced 512-B (256-B for the two
+// 32-bit fields) transaction, and every field of an entry sits at a compile-time offset from ONE per-lane address.
+// That keeps the whole queue behind a single pointer (2 SGPRs instead of 24 for twelve separate arrays) and lets the
+// loads use immediate offsets.
 struct Queue {
-    double *ox, *oy, *oz, *dx, *dy, *dz, *tm; // ray (src/math/ray.rs:3-7)
-    double *bx, *by, *bz;                     // path throughput
-    uint32_t *pid;                            // path id within the pass
-    uint32_t *rn;                             // RNG draws consumed so far
+    char *base;
+    static constexpr uint32_t kTileBytes = 64 * 88;
+    __device__ __forceinline__ char *at(uint32_t i) const {
+        return base + (size_t)(i >> 6) * kTileBytes + (size_t)(i & 63u) * 8u;
+    }
+    __device__ __forceinline__ char *at32(uint32_t i) const {
+        return base + (size_t)(i >> 6) * kTileBytes + 5120u + (size_t)(i & 63u) * 4u;
+    }
+    __device__ __forceinline__ double &ox(uint32_t i) const { return *(double *)(at(i) + 0 * 512); }
+    __device__ __forceinline__ double &oy(uint32_t i) const { return *(double *)(at(i) + 1 * 512); }
+    __device__ __forceinline__ double &oz(uint32_t i) const { return *(double *)(at(i) + 2 * 512); }
+    __device__ __forceinline__ double &dx(uint32_t i) const { return *(double *)(at(i) + 3 * 512); }
+    __device__ __forceinline__ double &dy(uint32_t i) const { return *(double *)(at(i) + 4 * 512); }
+    __device__ __forceinline__ double &dz(uint32_t i) const { return *(double *)(at(i) + 5 * 512); }
+    __device__ __forceinline__ double &tm(uint32_t i) const { return *(double *)(at(i) + 6 * 512); }
+    __device__ __forceinline__ double &bx(uint32_t i) const { return *(double *)(at(i) + 7 * 512); }
+    __device__ __forceinline__ double &by(uint32_t i) const { return *(double *)(at(i) + 8 * 512); }
+    __device__ __forceinline__ double &bz(uint32_t i) const { return *(double *)(at(i) + 9 * 512); }
+    __device__ __forceinline__ uint32_t &pid(uint32_t i) const { return *(uint32_t *)(at32(i)); }
+    __device__ __forceinline__ uint32_t &rn(uint32_t i) const { return *(uint32_t *)(at32(i) + 256); }
 };
 
 struct CameraDev { // derived fields of Camera::new (src/camera.rs:25-51)
@@ -158,12 +180,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, uint6
             const double time = cam.time0 + g.next() * (cam.time1 - cam.time0);
             D3 direction = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
             D3 origin = cam.origin + offset;
-            q.ox[slot] = origin.x; q.oy[slot] = origin.y; q.oz[slot] = origin.z;
-            q.dx[slot] = direction.x; q.dy[slot] = direction.y; q.dz[slot] = direction.z;
-            q.tm[slot] = time;
-            q.bx[slot] = 1.0; q.by[slot] = 1.0; q.bz[slot] = 1.0;
-            q.pid[slot] = pid;
-            q.rn[slot] = g.n;
+            q.ox(slot) = origin.x; q.oy(slot) = origin.y; q.oz(slot) = origin.z;
+            q.dx(slot) = direction.x; q.dy(slot) = direction.y; q.dz(slot) = direction.z;
+            q.tm(slot) = time;
+            q.bx(slot) = 1.0; q.by(slot) = 1.0; q.bz(slot) = 1.0;
+            q.pid(slot) = pid;
+            q.rn(slot) = g.n;
             keys[pid] = g.key;
         }
         if (pid < n) { // radiance accumulator of the path, also for skipped pixels
@@ -214,11 +236,11 @@ __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, Extend
         const uint32_t local = (v >> a.sh.shift) * kBlock + threadIdx.x;
         if (local >= a.counts[s_id]) continue;
         const uint32_t i = s_id * a.sh.shard_cap + local;
-        const D3 wo = d3(q.ox[i], q.oy[i], q.oz[i]);
-        const D3 wd = d3(q.dx[i], q.dy[i], q.dz[i]);
-        const double time = q.tm[i];
+        const D3 wo = d3(q.ox(i), q.oy(i), q.oz(i));
+        const D3 wd = d3(q.dx(i), q.dy(i), q.dz(i));
+        const double time = q.tm(i);
         uint64_t pkey = 0;
-        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid[i]] : intersect_key(a.medium_seed, i);
+        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid(i)] : intersect_key(a.medium_seed, i);
 
         D3 o = wo, d = wd;
         D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
@@ -334,11 +356,11 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
         const bool valid = local < ns;
         const uint32_t i = s_id * a.sh.shard_cap + local;
         const uint32_t il = valid ? i : s_id * a.sh.shard_cap;
-        D3 o = d3(q.ox[il], q.oy[il], q.oz[il]);
-        D3 d = d3(q.dx[il], q.dy[il], q.dz[il]);
-        const double time = q.tm[il];
+        D3 o = d3(q.ox(il), q.oy(il), q.oz(il));
+        D3 d = d3(q.dx(il), q.dy(il), q.dz(il));
+        const double time = q.tm(il);
         uint64_t pkey = 0;
-        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid[il]] : intersect_key(a.medium_seed, il);
+        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid(il)] : intersect_key(a.medium_seed, il);
         D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
         double closest = a.t_max;
         int32_t best = -1;
@@ -367,8 +389,8 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
                     no = o;
                     nd = d;
                 } else { // back to the enclosing frame: world ray, then that frame's chain
-                    no = d3(q.ox[il], q.oy[il], q.oz[il]);
-                    nd = d3(q.dx[il], q.dy[il], q.dz[il]);
+                    no = d3(q.ox(il), q.oy(il), q.oz(il));
+                    nd = d3(q.dx(il), q.dy(il), q.dz(il));
                 }
                 apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, no, nd);
                 if (mine) {
@@ -405,8 +427,10 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
     }
 }
 
-// Closest hit over a box-free op list (see pt_scene_upload): every lane of the wave tests every primitive, in
-// stream order, with op records coming through the scalar cache. Must be called by all 64 lanes of a wave.
+// Closest hit over the fused kernels' op list (see pt_scene_upload): no BOX ops, and a primitive's transform chain
+// is spelled out as XFORM ops in front of it. Every lane of the wave tests every primitive, in stream order. Op
+// records come through the scalar cache, one iteration ahead of their use, so a wave never waits for the record it
+// is about to test. Must be called by all 64 lanes of a wave.
 template <bool X, bool MEDIA>
 __device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *ops, int32_t n_ops, D3 o, D3 d, double time,
                                             uint64_t pkey, uint32_t depth, double t_min, double t_max, double &closest,
@@ -414,16 +438,43 @@ __device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *op
     const D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
     closest = t_max;
     best = -1;
-    for (int32_t c = 0; c < n_ops; ++c) {
-        const DevOp op = load_op_uniform(ops + c);
-        const int kind = __builtin_amdgcn_readfirstlane(op.kind) & 0xff;
-        double t = 0.0;
-        int sub = 0;
-        bool hit;
-        if (MEDIA && kind == OP_MEDIUM) hit = medium_hit<X>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
-        else hit = prim_hit<X>(sv, op, o, d, inv, time, t_min, closest, t, sub);
-        closest = hit ? t : closest;
-        best = hit ? (op.leaf | (sub << 28)) : best;
+    D3 fo = o, fd = d; // the ray in the frame of the primitive that follows a run of XFORM ops
+    bool framed = false;
+    // The list ends with a sentinel EXIT op (a fused list holds no other), and the loop runs on the KIND of the
+    // record it holds. Scalar loads return out of order, so the compiler can only ever wait for all of them: with
+    // the loop test reading the current record, that wait falls before the loop and at the end of each iteration,
+    // after the iteration's arithmetic has been issued, and never right behind the prefetch of the next record.
+    (void)n_ops;
+    DevOp op = load_op_uniform(ops);
+    int kind = __builtin_amdgcn_readfirstlane(op.kind) & 0xff;
+    int32_t c = 0;
+    while (kind != OP_EXIT) {
+        c += 1;
+        const DevOp nxt = load_op_uniform(ops + c);
+        if (kind == OP_XFORM) {
+            const DevXform x{op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], op.d[5]};
+            xform_ray<X>(x, fo, fd);
+            framed = true;
+        } else {
+            double t = 0.0;
+            int sub = 0;
+            bool hit;
+            if (MEDIA && kind == OP_MEDIUM) {
+                hit = medium_hit<X>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
+            } else if (framed) {
+                const D3 finv = d3(M<X>::rcp(fd.x), M<X>::rcp(fd.y), M<X>::rcp(fd.z));
+                hit = prim_hit_framed<X>(sv, op, fo, fd, finv, time, t_min, closest, t, sub);
+                fo = o;
+                fd = d;
+                framed = false;
+            } else {
+                hit = prim_hit_framed<X>(sv, op, o, d, inv, time, t_min, closest, t, sub);
+            }
+            closest = hit ? t : closest;
+            best = hit ? (op.leaf | (sub << 28)) : best;
+        }
+        op = nxt;
+        kind = __builtin_amdgcn_readfirstlane(op.kind) & 0xff;
     }
 }
 
@@ -433,10 +484,12 @@ __device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *op
 __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz, uint32_t pid, D3 c) {
     // Adding an exact zero changes nothing; a NaN compares unequal to zero and is added, which keeps the
     // reference's NaN propagation (0 * x / 0 in src/trace.rs:217-220).
+    // A path id belongs to one lane of one launch at a time, so the hardware f64 add in L2 gives the same sum as a
+    // load / add / store here, without making the wave wait for the load.
     if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) {
-        lx[pid] += c.x;
-        ly[pid] += c.y;
-        lz[pid] += c.z;
+        unsafeAtomicAdd(&lx[pid], c.x);
+        unsafeAtomicAdd(&ly[pid], c.y);
+        unsafeAtomicAdd(&lz[pid], c.z);
     }
 }
 
@@ -484,31 +537,31 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
         D3 o, d;
         double ht = 0.0;
         int32_t id = -1;
+        uint64_t pkey = 0;
         if (FUSE) { // whole waves walk the op list together; lanes past the end trace the shard's first ray
             const uint32_t il = (i < n) ? i : s_id * sh.shard_cap;
-            o = d3(qi.ox[il], qi.oy[il], qi.oz[il]);
-            d = d3(qi.dx[il], qi.dy[il], qi.dz[il]);
-            time = qi.tm[il];
-            pid = qi.pid[il];
-            uint64_t pkey = 0;
-            if (FUSE == 2) pkey = keys[pid];
+            o = d3(qi.ox(il), qi.oy(il), qi.oz(il));
+            d = d3(qi.dx(il), qi.dy(il), qi.dz(il));
+            time = qi.tm(il);
+            pid = qi.pid(il);
+            pkey = keys[pid]; // fetched before the traversal so that its latency hides behind it
             extend_list<X, FUSE == 2>(sv, sv.ops, sv.n_traversal_ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
         }
         if (i < n) {
             if (!FUSE) {
-                o = d3(qi.ox[i], qi.oy[i], qi.oz[i]);
-                d = d3(qi.dx[i], qi.dy[i], qi.dz[i]);
-                time = qi.tm[i];
-                pid = qi.pid[i];
+                o = d3(qi.ox(i), qi.oy(i), qi.oz(i));
+                d = d3(qi.dx(i), qi.dy(i), qi.dz(i));
+                time = qi.tm(i);
+                pid = qi.pid(i);
                 id = hit_id[i];
                 ht = hit_t[i];
             }
-            const D3 beta = d3(qi.bx[i], qi.by[i], qi.bz[i]);
+            const D3 beta = d3(qi.bx(i), qi.by(i), qi.bz(i));
             if (id < 0) {
                 // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
-                Rng g{keys[pid], qi.rn[i]};
+                Rng g{FUSE ? pkey : keys[pid], qi.rn(i)};
                 const DevLeaf *lfp; // fields are fetched where they are used
                 if constexpr (FUSE != 0) lfp = &s_leaves[id & 0x0fffffff].l;
                 else lfp = &sv.leaves[id & 0x0fffffff];
@@ -627,12 +680,12 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
         }
         const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], lds);
         if (alive) {
-            qo.ox[slot] = no.x; qo.oy[slot] = no.y; qo.oz[slot] = no.z;
-            qo.dx[slot] = nd.x; qo.dy[slot] = nd.y; qo.dz[slot] = nd.z;
-            qo.tm[slot] = time;
-            qo.bx[slot] = nbeta.x; qo.by[slot] = nbeta.y; qo.bz[slot] = nbeta.z;
-            qo.pid[slot] = pid;
-            qo.rn[slot] = rn;
+            qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
+            qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
+            qo.tm(slot) = time;
+            qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
+            qo.pid(slot) = pid;
+            qo.rn(slot) = rn;
         }
     }
 }
@@ -694,9 +747,16 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const doub
 __global__ __launch_bounds__(kBlock) void k_load_rays(const pt_ray *rays, uint32_t n, Queue q) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const pt_ray r = rays[i];
-        q.ox[i] = r.origin[0]; q.oy[i] = r.origin[1]; q.oz[i] = r.origin[2];
-        q.dx[i] = r.direction[0]; q.dy[i] = r.direction[1]; q.dz[i] = r.direction[2];
-        q.tm[i] = r.time;
+        q.ox(i) = r.origin[0]; q.oy(i) = r.origin[1]; q.oz(i) = r.origin[2];
+        q.dx(i) = r.direction[0]; q.dy(i) = r.direction[1]; q.dz(i) = r.direction[2];
+        q.tm(i) = r.time;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_load_rays_soa(const double *soa, uint32_t n, Queue q) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        q.ox(i) = soa[i]; q.oy(i) = soa[(size_t)n + i]; q.oz(i) = soa[2 * (size_t)n + i];
+        q.dx(i) = soa[3 * (size_t)n + i]; q.dy(i) = soa[4 * (size_t)n + i]; q.dz(i) = soa[5 * (size_t)n + i];
+        q.tm(i) = soa[6 * (size_t)n + i];
     }
 }
 template <bool X>
@@ -713,8 +773,8 @@ __global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, Scen
             h.material = -1;
         } else {
             const DevLeaf lf = sv.leaves[id & 0x0fffffff];
-            const HitRec rec = finalize_hit<X, true>(sv, lf, d3(q.ox[i], q.oy[i], q.oz[i]),
-                                                     d3(q.dx[i], q.dy[i], q.dz[i]), q.tm[i], hit_t[i], (id >> 28) & 7);
+            const HitRec rec = finalize_hit<X, true>(sv, lf, d3(q.ox(i), q.oy(i), q.oz(i)),
+                                                     d3(q.dx(i), q.dy(i), q.dz(i)), q.tm(i), hit_t[i], (id >> 28) & 7);
             h.t = rec.t; h.u = rec.u; h.v = rec.v;
             h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
             h.normal[0] = rec.n.x; h.normal[1] = rec.n.y; h.normal[2] = rec.n.z;
@@ -786,6 +846,9 @@ struct pt_ctx {
     int list_max_leaves = 24;
     void *d_ops_list = nullptr;
     int32_t n_list_ops = 0;
+    bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
+    void *d_ops_fused = nullptr;
+    int32_t n_fused_ops = 0;
     std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
     uint32_t profile_n = 0;        // its path count
 };
@@ -855,12 +918,7 @@ int alloc_path_state(pt_ctx *ctx) {
     };
     for (int k = 0; k < 2; ++k) {
         Queue &q = ctx->q[k];
-        q.ox = (double *)take(n * 8); q.oy = (double *)take(n * 8); q.oz = (double *)take(n * 8);
-        q.dx = (double *)take(n * 8); q.dy = (double *)take(n * 8); q.dz = (double *)take(n * 8);
-        q.tm = (double *)take(n * 8);
-        q.bx = (double *)take(n * 8); q.by = (double *)take(n * 8); q.bz = (double *)take(n * 8);
-        q.pid = (uint32_t *)take(n * 4);
-        q.rn = (uint32_t *)take(n * 4);
+        q.base = (char *)take((n / 64) * (size_t)Queue::kTileBytes); // n is a multiple of kBlock
     }
     ctx->d_keys = (uint64_t *)take(n * 8);
     for (int k = 0; k < 3; ++k) ctx->d_l[k] = (double *)take(n * 8);
@@ -946,8 +1004,8 @@ template <bool X, bool UV, int FUSE>
 void launch_shade_xuf(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
     SceneView v = ctx->view;
     if (FUSE) {
-        v.ops = (const DevOp *)ctx->d_ops_list;
-        v.n_traversal_ops = ctx->n_list_ops;
+        v.ops = (const DevOp *)ctx->d_ops_fused;
+        v.n_traversal_ops = ctx->n_fused_ops;
     }
     hipLaunchKernelGGL((k_shade<X, UV, FUSE>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
                        ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, v, ctx->d_hit_t,
@@ -987,7 +1045,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const bool realtime = pp.mode == PT_MODE_REALTIME;
     const bool profile = (ctx->flags & PT_CFG_PROFILE_STAGES) && (ctx->pass_counter % ctx->profile_period == 0);
     const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
-    const bool fused = ctx->fuse && ctx->scan_list && !ctx->exact && !count && !ctx->view.has_frames;
+    const bool fused = ctx->fuse && ctx->scan_list && ctx->fuse_ok && !ctx->exact && !count;
     ctx->pass_counter++;
     hipStream_t st = ctx->stream;
     const uint32_t iters = pp.max_depth + 1;
@@ -1129,7 +1187,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
-                    ctx->d_ops_list,
+                    ctx->d_ops_list, ctx->d_ops_fused,
                     ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1198,6 +1256,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     // tests cost more than the primitive tests they guard. Fast mode therefore scans the primitive ops alone, in the
     // same order; exact mode keeps every box test, i.e. the reference's culling decisions, ray by ray.
     ctx->scan_list = false;
+    ctx->fuse_ok = false;
     if (ctx->use_scan && !ctx->exact) {
         std::vector<DevOp> list;
         for (int32_t k = 0; k < f.n_traversal_ops; ++k)
@@ -1219,6 +1278,39 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
             for (size_t k = (size_t)f.n_traversal_ops; k < f.ops.size(); ++k) list.push_back(f.ops[k]); // boundaries
             if ((rc = upload(ctx, &ctx->d_ops_list, list.data(), list.size())) != PT_OK) return rc;
             ctx->scan_list = true;
+            // The fused trace+shade kernels read a second form of the list, in which a primitive's transform
+            // chain is written out as XFORM ops in front of it: the chain then arrives with the op stream instead
+            // of through a dependent load. (MEDIUM ops keep their chain and their boundary-op index.)
+            ctx->fuse_ok = !f.has_frames;
+            if (ctx->fuse_ok) {
+                std::vector<DevOp> fl;
+                const size_t n_list = (size_t)ctx->n_list_ops;
+                for (size_t k = 0; k < n_list; ++k) {
+                    DevOp op = list[k];
+                    const int kind = op_kind(op.kind);
+                    const int cc = (op.kind >> 16) & 0xff;
+                    if (kind != OP_MEDIUM && cc > 0) {
+                        for (int j = 0; j < cc; ++j) {
+                            const DevXform &x = f.xforms[(size_t)op.chain_start + j];
+                            DevOp xo;
+                            std::memset(&xo, 0, sizeof(xo));
+                            xo.d[0] = x.tx; xo.d[1] = x.ty; xo.d[2] = x.tz;
+                            xo.d[3] = x.s; xo.d[4] = x.c; xo.d[5] = x.sign;
+                            xo.kind = op_pack(OP_XFORM, 0, 0);
+                            xo.leaf = -1;
+                            fl.push_back(xo);
+                        }
+                        op.kind &= 0x0000ffff; // the chain is spent
+                    }
+                    fl.push_back(op);
+                }
+                ctx->n_fused_ops = (int32_t)fl.size();
+                for (DevOp &op : fl) // boundary ops follow the sentinel of THIS list
+                    if (op_kind(op.kind) == OP_MEDIUM)
+                        op.skip = op.skip - (int32_t)n_list + ctx->n_fused_ops;
+                for (size_t k = n_list; k < list.size(); ++k) fl.push_back(list[k]); // sentinel + boundary ops
+                if ((rc = upload(ctx, &ctx->d_ops_fused, fl.data(), fl.size())) != PT_OK) return rc;
+            }
         }
     }
     ctx->profile.clear();
@@ -1435,11 +1527,8 @@ int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double 
     if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_intersect_device before pt_scene_upload");
     if (n > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "ray batch larger than the paths-in-flight budget");
     (void)hipSetDevice(ctx->device);
-    Queue &q = ctx->q[0];
-    double *dst[7] = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, q.tm};
-    for (int k = 0; k < 7; ++k)
-        HIP_TRY(ctx, hipMemcpyAsync(dst[k], d_rays_soa + (size_t)k * n, n * sizeof(double), hipMemcpyDeviceToDevice,
-                                    ctx->stream));
+    hipLaunchKernelGGL(k_load_rays_soa, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, d_rays_soa, (uint32_t)n,
+                       ctx->q[0]);
     return intersect_common(ctx, n, t_min, t_max, medium_seed, repeats, mean_ms_out);
 }
 
