@@ -31,11 +31,13 @@ def algorithmic_bytes(V, P):
     """Per-unit HBM bytes of the compact layout the roofline is priced on: a ray is 28 B (f32 origin, direction,
     time), a hit 8 B, a BVH node / primitive / material record 32 B, a queue entry 48 B (ray + pixel + throughput).
     extend: read ray, write hit, fetch V nodes + P primitives. shade: read queue entry + hit, fetch primitive +
-    material, write the next queue entry. The fused trace+shade kernel does both on one queue entry and never
-    writes or re-reads the hit."""
+    material, write the next queue entry; together B_seg = 204 + 32 (V + P).
+    The fused trace+shade kernel does both on one queue entry and never writes or re-reads the hit. It only runs for
+    scenes whose whole geometry (a few KB) stays on chip, so no node or primitive fetch has to come from HBM: what
+    must cross HBM per segment is the queue entry in, the primitive + material records, and the queue entry out."""
     b_ray = 28 + 8 + 32.0 * (V + P)
     b_shade = 48 + 8 + 32 + 32 + 48
-    b_fused = 48 + 32.0 * (V + P) + 32 + 32 + 48
+    b_fused = 48 + 32 + 32 + 48
     return b_ray, b_shade, b_fused
 
 
@@ -76,6 +78,7 @@ def main():
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--paths-in-flight", type=int, default=1 << 24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode side measurement")
     args = ap.parse_args()
 
     import torch
@@ -140,6 +143,17 @@ def main():
         elapsed = float(t.item())
 
     st = ctx.stats()
+    exact_value = None
+    if rank == 0 and world == 1 and not args.no_exact:
+        # the same workload in exact mode (IEEE division, no contraction, every BVH box test): reported, not `value`
+        ctx_x = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight, flags=pt.PT_CFG_EXACT)
+        ctx_x.upload(scene)
+        spp_x = max(1, min(args.spp, 32))
+        ctx_x.render(W, H, spp_x, args.max_depth, frame=0)  # warm-up
+        t_x = time.perf_counter()
+        ctx_x.render(W, H, spp_x, args.max_depth, frame=1)
+        exact_value = float(W) * H * spp_x / (time.perf_counter() - t_x) / 1e6
+        ctx_x.close()
     paths_total = float(W) * H * args.spp * args.steps
     value = paths_total / elapsed / 1e6
     result = None
@@ -191,6 +205,9 @@ def main():
                 "paths_in_flight": args.paths_in_flight,
                 "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
                 "nan_pixel_fraction": nan_frac,
+                "arithmetic": "f64 rays, intersections and throughput; f32 direction sampling and pdf weights; "
+                              "reciprocal + Newton instead of IEEE division (PT_CFG_EXACT switches all of that off)",
+                "exact_mode_Mpaths_s": exact_value,
             },
             "roofline": {
                 "bound": "hbm",
@@ -209,6 +226,10 @@ def main():
                 "profiled_launches": n_launch,
                 "other": {
                     "fused_trace_shade": fused,
+                    # the unfused two-kernel figure 204 + 32 (V + P), which prices every node / primitive visit as
+                    # an HBM fetch, and the rate it would give; not used for `achieved`
+                    "two_kernel_bytes_per_segment": b_ray + b_shade,
+                    "two_kernel_model_GBs": seg * (b_ray + b_shade) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None,
                     "extend_ms_total": None if fused else ext_ms,
                     "shade_ms_total": shd_ms,
                     "raygen_ms_total": st.ms_raygen,

@@ -99,6 +99,20 @@ PT_DEV double fast_rcp(double y) {
     // y = 0 or inf: the refinement produces NaN (0 * inf); keep the hardware's inf / 0, as IEEE division would
     return (__builtin_isinf(r0) || r0 == 0.0) ? r0 : r;
 }
+// 1 / sqrt(x) for finite x > 0: hardware estimate (about 2^-23 relative) and two Newton steps.
+PT_DEV double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    y = __builtin_fma(y * 0.5, e, y);
+    e = __builtin_fma(-(x * y), y, 1.0);
+    y = __builtin_fma(y * 0.5, e, y);
+    return y;
+}
+// sqrt(x) for finite x >= 0 (x = 0 gives 0, not 0 * inf)
+PT_DEV double fast_sqrt(double x) {
+    const double r = x * fast_rsqrt(x);
+    return x == 0.0 ? 0.0 : r;
+}
 template <bool X> struct M {
     static PT_DEV double rcp(double y) {
         if constexpr (X) return 1.0 / y;
@@ -117,7 +131,10 @@ template <bool X> struct M {
         else return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x));
     }
     static PT_DEV double squared_length(D3 a) { return dot(a, a); }
-    static PT_DEV double length(D3 a) { return sqrt(dot(a, a)); }
+    static PT_DEV double length(D3 a) {
+        if constexpr (X) return sqrt(dot(a, a));
+        else return fast_sqrt(dot(a, a));
+    }
     static PT_DEV D3 divs(D3 a, double s) {
         if constexpr (X) return D3{a.x / s, a.y / s, a.z / s};
         else {
@@ -125,7 +142,13 @@ template <bool X> struct M {
             return D3{a.x * r, a.y * r, a.z * r};
         }
     }
-    static PT_DEV D3 unit_vector(D3 a) { return divs(a, length(a)); }
+    static PT_DEV D3 unit_vector(D3 a) {
+        if constexpr (X) return divs(a, length(a));
+        else {
+            const double r = fast_rsqrt(dot(a, a));
+            return D3{a.x * r, a.y * r, a.z * r};
+        }
+    }
     static PT_DEV D3 point_at(D3 o, D3 d, double t) { // Ray::point_at_parameter, src/math/ray.rs:30-32
         if constexpr (X) return D3{o.x + d.x * t, o.y + d.y * t, o.z + d.z * t};
         else return D3{__builtin_fma(d.x, t, o.x), __builtin_fma(d.y, t, o.y), __builtin_fma(d.z, t, o.z)};

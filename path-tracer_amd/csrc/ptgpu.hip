@@ -427,54 +427,176 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
     }
 }
 
+// ---- straight-line (predicated) primitive tests for the fused list walk, fast mode only -----------------------
+// The whole wave runs every test, so an early return saves nothing and costs an exec-mask branch; these forms
+// compute every lane to the end and return the acceptance as one predicate. Comparisons are written negated
+// (!(t < t_min)) where the reference's form lets a NaN through.
+
+// AxisAlignedRect::hit acceptance (src/rect.rs:97-105) for one plane axis
+template <int AXIS>
+__device__ __forceinline__ bool rect_pred_axis(const double *p, D3 o, D3 d, D3 inv, double t_min, double t_max,
+                                               double &t) {
+    const double ok = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z);
+    const double ik = AXIS == 0 ? inv.x : (AXIS == 1 ? inv.y : inv.z);
+    const double oa = AXIS == 0 ? o.y : o.x, da = AXIS == 0 ? d.y : d.x;
+    const double ob = AXIS == 2 ? o.y : o.z, db = AXIS == 2 ? d.y : d.z;
+    t = (p[4] - ok) * ik;
+    const double a = __builtin_fma(t, da, oa), b = __builtin_fma(t, db, ob);
+    return !(t < t_min) & !(t > t_max) & !(a < p[0]) & !(a > p[1]) & !(b < p[2]) & !(b > p[3]);
+}
+__device__ __forceinline__ bool rect_pred(const double *p, int axis, D3 o, D3 d, D3 inv, double t_min, double t_max,
+                                          double &t) {
+    if (axis == 0) return rect_pred_axis<0>(p, o, d, inv, t_min, t_max, t); // axis is wave-uniform
+    if (axis == 1) return rect_pred_axis<1>(p, o, d, inv, t_min, t_max, t);
+    return rect_pred_axis<2>(p, o, d, inv, t_min, t_max, t);
+}
+// Sphere::hit root selection (src/sphere.rs:44-81); dd = d.d and inv_dd = 1/dd are per-ray constants
+__device__ __forceinline__ bool sphere_pred(D3 c, double radius, D3 o, D3 d, double dd, double inv_dd, double t_min,
+                                            double t_max, double &t, int &which) {
+    const D3 oc = o - c;
+    const double b = M<false>::dot(oc, d);
+    const double cc = __builtin_fma(-radius, radius, M<false>::dot(oc, oc));
+    const double disc = __builtin_fma(-dd, cc, b * b);
+    const double root = fast_sqrt(disc); // garbage when disc <= 0; the predicate discards it
+    const double t0 = (-b - root) * inv_dd, t1 = (-b + root) * inv_dd;
+    const bool ok0 = (t0 < t_max) & (t0 > t_min), ok1 = (t1 < t_max) & (t1 > t_min);
+    t = ok0 ? t0 : t1;
+    which = ok0 ? 0 : 1;
+    return (disc > 0.0) & (ok0 | ok1);
+}
+// AxisAlignedBox::hit (src/axis_aligned_box.rs:17-40): six rectangle tests with a shrinking t_max find the nearer
+// of the (at most two) faces the ray crosses inside [t_min, t_max]. The slab form finds the same pair directly:
+// entry = latest near plane, exit = earliest far plane; the face is the plane that set it. Ties go to X, then Y,
+// then Z, as the reference's face order (+Z -Z +Y -Y +X -X, later face wins an equal t) gives.
+__device__ __forceinline__ bool box_pred(const double *pb, D3 o, D3 inv, double t_min, double t_max, double &t,
+                                         int &face) {
+    const double x0 = (pb[0] - o.x) * inv.x, x1 = (pb[3] - o.x) * inv.x;
+    const double y0 = (pb[1] - o.y) * inv.y, y1 = (pb[4] - o.y) * inv.y;
+    const double z0 = (pb[2] - o.z) * inv.z, z1 = (pb[5] - o.z) * inv.z;
+    const double nx = fmin(x0, x1), fx = fmax(x0, x1);
+    const double ny = fmin(y0, y1), fy = fmax(y0, y1);
+    const double nz = fmin(z0, z1), fz = fmax(z0, z1);
+    const double tn = fmax(nx, fmax(ny, nz)), tf = fmin(fx, fmin(fy, fz));
+    const bool entry = !(tn < t_min);
+    t = entry ? tn : tf;
+    const int axis_n = (nx == tn) ? 0 : ((ny == tn) ? 1 : 2);
+    const int axis_f = (fx == tf) ? 0 : ((fy == tf) ? 1 : 2);
+    const int axis = entry ? axis_n : axis_f;
+    const double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
+    // entering through the max plane means travelling in -axis; leaving through it, in +axis
+    const bool max_plane = entry ? (ia < 0.0) : (ia > 0.0);
+    face = (2 - axis) * 2 + (max_plane ? 0 : 1);
+    return (tn <= tf) & !(t < t_min) & !(t > t_max);
+}
+
 // Closest hit over the fused kernels' op list (see pt_scene_upload): no BOX ops, and a primitive's transform chain
 // is spelled out as XFORM ops in front of it. Every lane of the wave tests every primitive, in stream order. Op
 // records come through the scalar cache, one iteration ahead of their use, so a wave never waits for the record it
-// is about to test. Must be called by all 64 lanes of a wave.
-template <bool X, bool MEDIA>
-__device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *ops, int32_t n_ops, D3 o, D3 d, double time,
-                                            uint64_t pkey, uint32_t depth, double t_min, double t_max, double &closest,
-                                            int32_t &best) {
-    const D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-    closest = t_max;
-    best = -1;
-    D3 fo = o, fd = d; // the ray in the frame of the primitive that follows a run of XFORM ops
-    bool framed = false;
-    // The list ends with a sentinel EXIT op (a fused list holds no other), and the loop runs on the KIND of the
-    // record it holds. Scalar loads return out of order, so the compiler can only ever wait for all of them: with
-    // the loop test reading the current record, that wait falls before the loop and at the end of each iteration,
-    // after the iteration's arithmetic has been issued, and never right behind the prefetch of the next record.
-    (void)n_ops;
-    DevOp op = load_op_uniform(ops);
-    int kind = __builtin_amdgcn_readfirstlane(op.kind) & 0xff;
-    int32_t c = 0;
-    while (kind != OP_EXIT) {
-        c += 1;
-        const DevOp nxt = load_op_uniform(ops + c);
-        if (kind == OP_XFORM) {
+// is about to test. Must be called by all 64 lanes of a wave. Fast mode only.
+constexpr int kOpFramed = 1 << 24; // fused lists: the primitive is tested against the frame ray set up by XFORM ops
+constexpr int kOpFirst = 1 << 25;  // fused lists: this XFORM op starts a chain (from the world ray)
+
+template <bool MEDIA> struct ListWalk {
+    const SceneView &sv;
+    D3 o, d, inv;    // world ray
+    D3 fo, fd, finv; // the ray in the frame of the primitive that follows a run of XFORM ops
+    double dd, inv_dd, time, t_min, closest;
+    uint64_t pkey;
+    uint32_t depth;
+    int32_t best;
+
+    __device__ __forceinline__ void test(const DevOp &op, int kword, D3 po, D3 pd, D3 pinv) {
+        const int kind = kword & 0xff;
+        double t = 0.0;
+        int sub = 0;
+        bool hit;
+        if (kind == OP_RECT) hit = rect_pred(op.d, (kword >> 8) & 3, po, pd, pinv, t_min, closest, t);
+        else if (kind == OP_SPHERE)
+            hit = sphere_pred(d3(op.d[0], op.d[1], op.d[2]), op.d[3], po, pd, dd, inv_dd, t_min, closest, t, sub);
+        else if (kind == OP_BOXPRIM) hit = box_pred(op.d, po, pinv, t_min, closest, t, sub);
+        else if (MEDIA && kind == OP_MEDIUM)
+            hit = medium_hit<false>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
+        else hit = prim_hit_framed<false>(sv, op, po, pd, pinv, time, t_min, closest, t, sub);
+        closest = hit ? t : closest;
+        best = hit ? (op.leaf | (sub << 28)) : best;
+    }
+    // kword is wave-uniform, so these are scalar branches between straight-line blocks (no per-lane selects)
+    __device__ __forceinline__ void step(const DevOp &op, int kword) {
+        if ((kword & 0xff) == OP_XFORM) {
             const DevXform x{op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], op.d[5]};
-            xform_ray<X>(x, fo, fd);
-            framed = true;
-        } else {
-            double t = 0.0;
-            int sub = 0;
-            bool hit;
-            if (MEDIA && kind == OP_MEDIUM) {
-                hit = medium_hit<X>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
-            } else if (framed) {
-                const D3 finv = d3(M<X>::rcp(fd.x), M<X>::rcp(fd.y), M<X>::rcp(fd.z));
-                hit = prim_hit_framed<X>(sv, op, fo, fd, finv, time, t_min, closest, t, sub);
+            if (kword & kOpFirst) {
                 fo = o;
                 fd = d;
-                framed = false;
-            } else {
-                hit = prim_hit_framed<X>(sv, op, o, d, inv, time, t_min, closest, t, sub);
+                finv = inv;
             }
-            closest = hit ? t : closest;
-            best = hit ? (op.leaf | (sub << 28)) : best;
+            xform_ray<false>(x, fo, fd);
+            if (x.s != 0.0) finv = d3(fast_rcp(fd.x), finv.y, fast_rcp(fd.z)); // a Y rotation leaves d.y alone
+        } else if (kword & kOpFramed) {
+            test(op, kword, fo, fd, finv);
+        } else {
+            test(op, kword, o, d, inv);
         }
-        op = nxt;
-        kind = __builtin_amdgcn_readfirstlane(op.kind) & 0xff;
+    }
+};
+
+// Closest hit over the fused kernels' op list (see pt_scene_upload): no BOX ops, and a primitive's transform chain
+// is spelled out as XFORM ops in front of it. Every lane of the wave tests every primitive, in stream order. Op
+// records come through the scalar cache, one iteration ahead of their use, so a wave never waits for the record it
+// is about to test. Must be called by all 64 lanes of a wave. Fast mode only.
+template <bool MEDIA>
+__device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *ops, D3 o, D3 d, double time,
+                                            uint64_t pkey, uint32_t depth, double t_min, double t_max, double &closest,
+                                            int32_t &best) {
+    const D3 inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+    const double dd = M<false>::dot(d, d); // unchanged by the rigid XFORM steps
+    ListWalk<MEDIA> w{sv, o, d, inv, o, d, inv, dd, fast_rcp(dd), time, t_min, t_max, pkey, depth, -1};
+    // The list ends with a sentinel EXIT op (a fused list holds no other), and the loop runs on the KIND of the
+    // record it holds. Scalar loads return out of order, so the compiler can only ever wait for all of them: with
+    // the loop test reading the current record, that wait falls before the loop and at the end of each step, after
+    // the step's arithmetic has been issued, and never right behind the prefetch of the next record. Two records
+    // alternate (a, b) so that no record is ever copied.
+    DevOp a = load_op_uniform(ops);
+    int ka = __builtin_amdgcn_readfirstlane(a.kind);
+    for (int32_t c = 0;; c += 2) {
+        if ((ka & 0xff) == OP_EXIT) break;
+        const DevOp b = load_op_uniform(ops + c + 1);
+        w.step(a, ka);
+        const int kb = __builtin_amdgcn_readfirstlane(b.kind);
+        if ((kb & 0xff) == OP_EXIT) break;
+        a = load_op_uniform(ops + c + 2);
+        w.step(b, kb);
+        ka = __builtin_amdgcn_readfirstlane(a.kind);
+    }
+    closest = w.closest;
+    best = w.best;
+}
+
+// Extend stage on its own over a fused-kernel op list: the same walk the fused trace+shade kernels run, for ray
+// batches (pt_intersect) and for passes that keep trace and shade apart.
+template <bool MEDIA>
+__global__ __launch_bounds__(kBlock) void k_extend_list(Queue q, SceneView sv, ExtendArgs a) {
+    const uint32_t n_virtual = ((max_shard_count(a.counts, a.sh.shards) + kBlock - 1) / kBlock) << a.sh.shift;
+    for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+        const uint32_t s_id = v & (a.sh.shards - 1);
+        const uint32_t ns = a.counts[s_id];
+        const uint32_t row0 = (v >> a.sh.shift) * kBlock;
+        if (row0 >= ns) continue;
+        const uint32_t local = row0 + threadIdx.x;
+        const bool valid = local < ns;
+        const uint32_t i = s_id * a.sh.shard_cap + local;
+        const uint32_t il = valid ? i : s_id * a.sh.shard_cap;
+        const D3 o = d3(q.ox(il), q.oy(il), q.oz(il));
+        const D3 d = d3(q.dx(il), q.dy(il), q.dz(il));
+        const double time = q.tm(il);
+        uint64_t pkey = 0;
+        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid(il)] : intersect_key(a.medium_seed, il);
+        double closest;
+        int32_t best;
+        extend_list<MEDIA>(sv, sv.ops, o, d, time, pkey, a.depth, a.t_min, a.t_max, closest, best);
+        if (valid) {
+            a.hit_t[i] = closest;
+            a.hit_id[i] = best;
+        }
     }
 }
 
@@ -545,7 +667,10 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
             time = qi.tm(il);
             pid = qi.pid(il);
             pkey = keys[pid]; // fetched before the traversal so that its latency hides behind it
-            extend_list<X, FUSE == 2>(sv, sv.ops, sv.n_traversal_ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
+            extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
+#ifdef PT_EXPERIMENT_MISS
+            id = ht > 1e300 ? id : -1;
+#endif
         }
         if (i < n) {
             if (!FUSE) {
@@ -978,7 +1103,12 @@ D3 hunit(D3 a) {
 
 template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
-    if (ctx->use_scan && ctx->scan_list) {
+    if (!X && !FRAMES && ctx->use_scan && ctx->scan_list && ctx->fuse_ok && ctx->fuse && a.counters == nullptr) {
+        SceneView v = ctx->view;
+        v.ops = (const DevOp *)ctx->d_ops_fused;
+        v.n_traversal_ops = ctx->n_fused_ops;
+        hipLaunchKernelGGL((k_extend_list<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, v, a);
+    } else if (ctx->use_scan && ctx->scan_list) {
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_list;
         v.n_traversal_ops = ctx->n_list_ops;
@@ -1296,11 +1426,11 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
                             std::memset(&xo, 0, sizeof(xo));
                             xo.d[0] = x.tx; xo.d[1] = x.ty; xo.d[2] = x.tz;
                             xo.d[3] = x.s; xo.d[4] = x.c; xo.d[5] = x.sign;
-                            xo.kind = op_pack(OP_XFORM, 0, 0);
+                            xo.kind = op_pack(OP_XFORM, 0, 0) | (j == 0 ? kOpFirst : 0);
                             xo.leaf = -1;
                             fl.push_back(xo);
                         }
-                        op.kind &= 0x0000ffff; // the chain is spent
+                        op.kind = (op.kind & 0x0000ffff) | kOpFramed; // the chain is spent
                     }
                     fl.push_back(op);
                 }
