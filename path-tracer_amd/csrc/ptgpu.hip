@@ -48,20 +48,21 @@ struct QueueShape {
 // ------------------------------------------------------------------------------------------------------------
 // Path-state queues (structure of arrays, one entry per in-flight ray)
 // ------------------------------------------------------------------------------------------------------------
-// An entry is 88 B: the ray (src/math/ray.rs:3-7), the path throughput, the path id within the pass and the number
-// of RNG draws consumed so far. Entries are stored in tiles of 64 (one wavefront): inside a tile every field is a
-// contiguous run of 64 values, so a wave's access to one field is one fully coalesced 512-B (256-B for the two
-// 32-bit fields) transaction, and every field of an entry sits at a compile-time offset from ONE per-lane address.
-// That keeps the whole queue behind a single pointer (2 SGPRs instead of 24 for twelve separate arrays) and lets the
-// loads use immediate offsets.
+// An entry is 96 B: the ray (src/math/ray.rs:3-7), the path throughput, the path's RNG key, the path id within the
+// pass and the number of RNG draws consumed so far. Entries are stored in tiles of 64 (one wavefront): inside a tile
+// every field is a contiguous run of 64 values, so a wave's access to one field is one fully coalesced 512-B (256-B
+// for the two 32-bit fields) transaction, and every field of an entry sits at a compile-time offset from ONE
+// per-lane address. That keeps the whole queue behind a single pointer (2 SGPRs instead of 26 for thirteen separate
+// arrays) and lets the loads use immediate offsets. A tile is 6 KiB of contiguous memory: exactly six
+// 1-KiB direct-to-LDS loads of one wave.
 struct Queue {
     char *base;
-    static constexpr uint32_t kTileBytes = 64 * 88;
+    static constexpr uint32_t kTileBytes = 64 * 96;
     __device__ __forceinline__ char *at(uint32_t i) const {
         return base + (size_t)(i >> 6) * kTileBytes + (size_t)(i & 63u) * 8u;
     }
     __device__ __forceinline__ char *at32(uint32_t i) const {
-        return base + (size_t)(i >> 6) * kTileBytes + 5120u + (size_t)(i & 63u) * 4u;
+        return base + (size_t)(i >> 6) * kTileBytes + 5632u + (size_t)(i & 63u) * 4u;
     }
     __device__ __forceinline__ double &ox(uint32_t i) const { return *(double *)(at(i) + 0 * 512); }
     __device__ __forceinline__ double &oy(uint32_t i) const { return *(double *)(at(i) + 1 * 512); }
@@ -73,6 +74,7 @@ struct Queue {
     __device__ __forceinline__ double &bx(uint32_t i) const { return *(double *)(at(i) + 7 * 512); }
     __device__ __forceinline__ double &by(uint32_t i) const { return *(double *)(at(i) + 8 * 512); }
     __device__ __forceinline__ double &bz(uint32_t i) const { return *(double *)(at(i) + 9 * 512); }
+    __device__ __forceinline__ uint64_t &key(uint32_t i) const { return *(uint64_t *)(at(i) + 10 * 512); }
     __device__ __forceinline__ uint32_t &pid(uint32_t i) const { return *(uint32_t *)(at32(i)); }
     __device__ __forceinline__ uint32_t &rn(uint32_t i) const { return *(uint32_t *)(at32(i) + 256); }
 };
@@ -129,6 +131,12 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *out_count
     return slot;
 }
 
+// A queue's fill counts were written by the launch before this one and do not change while a kernel reads them, so
+// they can come through the scalar cache (one s_load for the wave instead of a vector load per lane).
+__device__ __forceinline__ uint32_t shard_count(const uint32_t *counts, uint32_t s_id) {
+    return *(const uint32_t __attribute__((address_space(4))) *)(counts + s_id);
+}
+
 // Largest fill count over the shards of a queue (every lane of every wave gets the value).
 __device__ __forceinline__ uint32_t max_shard_count(const uint32_t *counts, uint32_t shards) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -145,7 +153,7 @@ __device__ __forceinline__ uint32_t max_shard_count(const uint32_t *counts, uint
 // raygen
 // ------------------------------------------------------------------------------------------------------------
 template <bool REALTIME>
-__global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, uint64_t *keys, double *lx, double *ly,
+__global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, double *lx, double *ly,
                                                    double *lz, CameraDev cam, PassParams pp, uint32_t *counts) {
     __shared__ uint32_t lds[kWavesPerBlock + 1];
     const uint32_t n = pp.cpix * pp.s_count;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, uint6
             q.bx(slot) = 1.0; q.by(slot) = 1.0; q.bz(slot) = 1.0;
             q.pid(slot) = pid;
             q.rn(slot) = g.n;
-            keys[pid] = g.key;
+            q.key(slot) = g.key;
         }
         if (pid < n) { // radiance accumulator of the path, also for skipped pixels
             lx[pid] = 0.0; ly[pid] = 0.0; lz[pid] = 0.0;
@@ -213,7 +221,6 @@ struct ExtendArgs {
     const uint32_t *counts; // fill count per shard of the queue
     QueueShape sh;
     double t_min, t_max;
-    const uint64_t *keys;  // key_mode 0: the path's key is keys[pid[i]] (render)
     uint64_t medium_seed;  // key_mode 1: intersect_key(medium_seed, i) (pt_intersect)
     uint32_t key_mode;
     uint32_t depth;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, Extend
         const D3 wd = d3(q.dx(i), q.dy(i), q.dz(i));
         const double time = q.tm(i);
         uint64_t pkey = 0;
-        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid(i)] : intersect_key(a.medium_seed, i);
+        if (MEDIA) pkey = (a.key_mode == 0) ? q.key(i) : intersect_key(a.medium_seed, i);
 
         D3 o = wo, d = wd;
         D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
         D3 d = d3(q.dx(il), q.dy(il), q.dz(il));
         const double time = q.tm(il);
         uint64_t pkey = 0;
-        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid(il)] : intersect_key(a.medium_seed, il);
+        if (MEDIA) pkey = (a.key_mode == 0) ? q.key(il) : intersect_key(a.medium_seed, il);
         D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
         double closest = a.t_max;
         int32_t best = -1;
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_list(Queue q, SceneView sv, E
         const D3 d = d3(q.dx(il), q.dy(il), q.dz(il));
         const double time = q.tm(il);
         uint64_t pkey = 0;
-        if (MEDIA) pkey = (a.key_mode == 0) ? a.keys[q.pid(il)] : intersect_key(a.medium_seed, il);
+        if (MEDIA) pkey = (a.key_mode == 0) ? q.key(il) : intersect_key(a.medium_seed, il);
         double closest;
         int32_t best;
         extend_list<MEDIA>(sv, sv.ops, o, d, time, pkey, a.depth, a.t_min, a.t_max, closest, best);
@@ -627,46 +634,109 @@ struct LdsLeaf {
 };
 constexpr int kLdsLeaves = 32; // the fused kernels keep the whole leaf table in LDS
 
+// LDS of one workgroup. Kept as ONE object: with a second __shared__ object beside a buffer that direct-to-LDS loads
+// fill, the compiler waits for those loads before every LDS read.
+template <int FUSE> struct ShadeLds {
+    uint32_t cnt[kWavesPerBlock + 1];
+    LdsLeaf leaves[1];
+    unsigned char tile[1][16];
+};
+template <> struct ShadeLds<1> {
+    alignas(16) unsigned char tile[kWavesPerBlock][Queue::kTileBytes]; // each wave's next queue tile
+    LdsLeaf leaves[kLdsLeaves];
+    uint32_t cnt[kWavesPerBlock + 1];
+};
+
+// Starts the copy of queue tile `tile` into the calling wave's LDS buffer: six 1-KiB direct-to-LDS loads (lane l
+// moves bytes [16 l, 16 l + 16) of every KiB; the instruction offset advances the global and the LDS address alike).
+// Nothing waits here. The loads are written in assembly on purpose: told about them, the compiler drains the VM
+// counter before EVERY later LDS read (it cannot tell the tile buffer from the leaf table), which would put the
+// whole HBM round trip back in front of the shading. The caller retires them with tile_wait() before it reads the
+// buffer.
+__device__ __forceinline__ void prefetch_tile(const Queue &q, uint32_t tile, unsigned char *lds_wave, uint32_t lane) {
+    typedef __attribute__((address_space(3))) unsigned char *LPtr;
+    const char *g0 = q.base + (size_t)tile * Queue::kTileBytes + lane * 16u;
+    const char *g1 = g0 + 4096;
+    const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(LPtr)lds_wave);
+    const uint32_t l1 = l0 + 4096u;
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:3072\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 :
+                 : "v"(g0), "v"(g1), "s"(l0), "s"(l1)
+                 : "memory", "m0");
+}
+// Every vector memory operation of the wave, the tile copy included, has completed.
+__device__ __forceinline__ void tile_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <bool X, bool NEED_UV, int FUSE>
 __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
                                                   uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
-                                                  const uint64_t *keys, double *lx, double *ly, double *lz,
+                                                  double *lx, double *ly, double *lz,
                                                   uint32_t depth, uint32_t max_depth) {
-    __shared__ uint32_t lds[kWavesPerBlock + 1];
-    __shared__ LdsLeaf s_leaves[FUSE ? kLdsLeaves : 1];
+    __shared__ ShadeLds<(FUSE != 0) ? 1 : 0> S;
+    uint32_t *lds = S.cnt;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_virtual = ((max_shard_count(n_in, sh.shards) + kBlock - 1) / kBlock) << sh.shift;
+    // first queue tile of virtual chunk v that this wave handles
+    auto tile_of = [&](uint32_t v) -> uint32_t {
+        return (((v & (sh.shards - 1)) * sh.shard_cap + (v >> sh.shift) * kBlock) >> 6) + wave;
+    };
     if constexpr (FUSE != 0) {
+        if (blockIdx.x < n_virtual) prefetch_tile(qi, tile_of(blockIdx.x), S.tile[wave], lane);
         // Shading gathers ~100 B of its leaf per lane through a chain of dependent loads (kind -> geometry ->
         // material); from LDS each link costs tens of cycles instead of an L1/L2 round trip.
         constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
         const double *src = (const double *)sv.leaves;
         for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
-            ((double *)&s_leaves[k / kWords].l)[k % kWords] = src[k];
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        tile_wait();
         __syncthreads();
     }
-    const uint32_t n_virtual = ((max_shard_count(n_in, sh.shards) + kBlock - 1) / kBlock) << sh.shift;
     for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
         const uint32_t s_id = v & (sh.shards - 1);
-        const uint32_t ns = n_in[s_id];
+        const uint32_t ns = shard_count(n_in, s_id);
         const uint32_t row0 = (v >> sh.shift) * kBlock;
-        if (row0 >= ns) continue; // uniform for the workgroup
-        const uint32_t local = row0 + threadIdx.x;
-        const uint32_t i = s_id * sh.shard_cap + local;
-        const uint32_t n = s_id * sh.shard_cap + ns; // first slot past this shard's entries
         bool alive = false;
         D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
         double time = 0.0;
         uint32_t pid = 0, rn = 0;
-        D3 o, d;
+        D3 o, d, beta;
         double ht = 0.0;
         int32_t id = -1;
         uint64_t pkey = 0;
-        if (FUSE) { // whole waves walk the op list together; lanes past the end trace the shard's first ray
-            const uint32_t il = (i < n) ? i : s_id * sh.shard_cap;
-            o = d3(qi.ox(il), qi.oy(il), qi.oz(il));
-            d = d3(qi.dx(il), qi.dy(il), qi.dz(il));
-            time = qi.tm(il);
-            pid = qi.pid(il);
-            pkey = keys[pid]; // fetched before the traversal so that its latency hides behind it
+        if constexpr (FUSE != 0) {
+            // This wave's tile was requested one iteration ago (or before the loop) and has had a whole trace + shade
+            // to arrive. Every field moves into registers, then the buffer is handed to the request for the tile of
+            // the next iteration, which the work below hides. Lanes past the shard's fill read stale entries: they
+            // are traced (whole waves walk the op list together) and dropped.
+            const unsigned char *e = S.tile[wave] + lane * 8u;
+            o = d3(*(const double *)(e + 0 * 512), *(const double *)(e + 1 * 512), *(const double *)(e + 2 * 512));
+            d = d3(*(const double *)(e + 3 * 512), *(const double *)(e + 4 * 512), *(const double *)(e + 5 * 512));
+            time = *(const double *)(e + 6 * 512);
+            beta = d3(*(const double *)(e + 7 * 512), *(const double *)(e + 8 * 512), *(const double *)(e + 9 * 512));
+            pkey = *(const uint64_t *)(e + 10 * 512);
+            pid = *(const uint32_t *)(S.tile[wave] + 5632 + lane * 4u);
+            rn = *(const uint32_t *)(S.tile[wave] + 5888 + lane * 4u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads are done before the buffer is refilled
+            const uint32_t vn = v + gridDim.x;
+            if (vn < n_virtual) prefetch_tile(qi, tile_of(vn), S.tile[wave], lane);
+        }
+        if (row0 >= ns) { // uniform for the workgroup
+            if constexpr (FUSE != 0) tile_wait();
+            continue;
+        }
+        const uint32_t local = row0 + threadIdx.x;
+        const uint32_t i = s_id * sh.shard_cap + local;
+        const uint32_t n = s_id * sh.shard_cap + ns; // first slot past this shard's entries
+        if (FUSE) {
             extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
 #ifdef PT_EXPERIMENT_MISS
             id = ht > 1e300 ? id : -1;
@@ -680,15 +750,17 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
                 pid = qi.pid(i);
                 id = hit_id[i];
                 ht = hit_t[i];
+                beta = d3(qi.bx(i), qi.by(i), qi.bz(i));
+                rn = qi.rn(i);
             }
-            const D3 beta = d3(qi.bx(i), qi.by(i), qi.bz(i));
             if (id < 0) {
                 // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
                 add_radiance(lx, ly, lz, pid, beta * 0.0);
             } else {
-                Rng g{FUSE ? pkey : keys[pid], qi.rn(i)};
+                if (!FUSE) pkey = qi.key(i);
+                Rng g{pkey, rn};
                 const DevLeaf *lfp; // fields are fetched where they are used
-                if constexpr (FUSE != 0) lfp = &s_leaves[id & 0x0fffffff].l;
+                if constexpr (FUSE != 0) lfp = &S.leaves[id & 0x0fffffff].l;
                 else lfp = &sv.leaves[id & 0x0fffffff];
                 const DevLeaf &lf = *lfp;
                 const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, ht, (id >> 28) & 7);
@@ -804,6 +876,9 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
             }
         }
         const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], lds);
+        // The next tile was requested a whole trace + shade ago; retiring it here, ahead of this iteration's stores,
+        // costs next to nothing, while a wait at the top of the loop would also sit out those stores.
+        if constexpr (FUSE != 0) tile_wait();
         if (alive) {
             qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
             qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
@@ -811,6 +886,7 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
             qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
             qo.pid(slot) = pid;
             qo.rn(slot) = rn;
+            qo.key(slot) = pkey;
         }
     }
 }
@@ -938,7 +1014,6 @@ struct pt_ctx {
     // path state
     void *d_pool = nullptr; // one allocation carved into the arrays below
     Queue q[2]{};
-    uint64_t *d_keys = nullptr;
     double *d_l[3] = {nullptr, nullptr, nullptr};
     double *d_hit_t = nullptr;
     int32_t *d_hit_id = nullptr;
@@ -1030,9 +1105,9 @@ int alloc_path_state(pt_ctx *ctx) {
     ctx->shape.shift = shift;
     ctx->shape.shard_cap = per_shard;
     const size_t n = ctx->capacity;
-    // 2 queues x (10 f64 + 2 u32) + keys + 3 f64 radiance + hit (f64 + i32)
-    const size_t per_path = 2 * (10 * 8 + 2 * 4) + 8 + 3 * 8 + 8 + 4;
-    const size_t n_arrays = 2 * 12 + 1 + 3 + 2;
+    // 2 queues x (10 f64 + key + 2 u32) + 3 f64 radiance + hit (f64 + i32)
+    const size_t per_path = 2 * 96 + 3 * 8 + 8 + 4;
+    const size_t n_arrays = 2 + 3 + 2;
     const size_t bytes = n * per_path + n_arrays * 256; // every array starts on a 256-byte boundary
     HIP_TRY(ctx, hipMalloc(&ctx->d_pool, bytes));
     char *p = (char *)ctx->d_pool;
@@ -1045,7 +1120,6 @@ int alloc_path_state(pt_ctx *ctx) {
         Queue &q = ctx->q[k];
         q.base = (char *)take((n / 64) * (size_t)Queue::kTileBytes); // n is a multiple of kBlock
     }
-    ctx->d_keys = (uint64_t *)take(n * 8);
     for (int k = 0; k < 3; ++k) ctx->d_l[k] = (double *)take(n * 8);
     ctx->d_hit_t = (double *)take(n * 8);
     ctx->d_hit_id = (int32_t *)take(n * 4);
@@ -1139,7 +1213,7 @@ void launch_shade_xuf(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, u
     }
     hipLaunchKernelGGL((k_shade<X, UV, FUSE>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
                        ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, v, ctx->d_hit_t,
-                       ctx->d_hit_id, ctx->d_keys, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth);
+                       ctx->d_hit_id, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth);
 }
 // fused = trace inside the shade kernel (fast mode, box-free list, no transformed subtrees)
 void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth, bool fused) {
@@ -1194,10 +1268,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const int g_all = grid_for(ctx, n);
     HIP_TRY(ctx, mark());
     if (realtime)
-        hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->shape, ctx->d_keys,
+        hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->shape,
                            ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
     else
-        hipLaunchKernelGGL(k_raygen<false>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->shape, ctx->d_keys,
+        hipLaunchKernelGGL(k_raygen<false>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], ctx->shape,
                            ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
     HIP_TRY(ctx, mark());
     for (uint32_t d = 0; d < iters; ++d) {
@@ -1209,7 +1283,6 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         ea.sh = ctx->shape;
         ea.t_min = 0.001; // src/trace.rs:205
         ea.t_max = kF64Max;
-        ea.keys = ctx->d_keys;
         ea.medium_seed = 0;
         ea.key_mode = 0;
         ea.depth = d;
@@ -1587,7 +1660,6 @@ static int intersect_common(pt_ctx *ctx, size_t n, double t_min, double t_max, u
     ea.sh = QueueShape{1u, 0u, ctx->capacity}; // one shard: slot == ray index
     ea.t_min = t_min;
     ea.t_max = t_max;
-    ea.keys = ctx->d_keys;
     ea.medium_seed = medium_seed;
     ea.key_mode = 1;
     ea.depth = 0;
