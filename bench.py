@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--scene", default="cornell_box")
-    ap.add_argument("--paths-in-flight", type=int, default=1 << 24)
+    ap.add_argument("--paths-in-flight", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode side measurement")
     args = ap.parse_args()

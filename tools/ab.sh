@@ -6,7 +6,7 @@ cp path-tracer_amd/libptgpu.so /tmp/base.so
 for lib in base "$@"; do
   if [ "$lib" = base ]; then cp /tmp/base.so path-tracer_amd/libptgpu.so; else cp "$lib" path-tracer_amd/libptgpu.so; fi
   for rep in 1 2; do
-    timeout -k 10 200 python3 bench.py --spp 64 --steps 3 --no-cpu-baseline > /tmp/ab.json
+    timeout -k 10 200 python3 bench.py --spp 64 --steps 3 --no-cpu-baseline --no-exact > /tmp/ab.json
     python3 - "$lib" <<'PY'
 import json, sys
 r = json.load(open('/tmp/ab.json'))
