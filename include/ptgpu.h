@@ -310,6 +310,17 @@ int pt_scene_flatten_info(const pt_scene_desc *scene, int32_t *n_ops, int32_t *n
  * (src/trace.rs:236-242, src/lib.rs:330-340,613-640). rgb8_out is width*height*3, top row first. */
 int pt_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8_out);
 
+/* The same conversion on the device, from the context's image (src/trace.rs:236-242, src/lib.rs:330-340,613-640):
+ * rgb8_out is a HOST buffer of width*height*3 bytes, top row first. Bit-identical to pt_tonemap_rgb8. */
+int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes);
+
+/* Replaces the rendy tonemap pass, assets/shaders/tonemap.frag:37-70 (exposure from TonemapperArgs,
+ * src/lib.rs:284-286: 1.3 by default; keys change it, src/lib.rs:425-429): colour * exposure, ACES-fitted curve
+ * (input matrix, RRT+ODT fit, output matrix, clamp to [0,1]), times the vignette 1 - |uv - (0.5,0.5)| at the
+ * fragment centre; f32 arithmetic as in the shader. rgba_out is a HOST buffer of width*height*4 floats, row 0 = top
+ * of the screen (the shader's uv.y flip), alpha 1. */
+int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_floats);
+
 uint32_t pt_abi_version(void);
 
 #ifdef __cplusplus

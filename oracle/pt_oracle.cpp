@@ -1284,4 +1284,37 @@ int oracle_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint
     return 0;
 }
 
+/* The display transform of the rendy tonemap pass (assets/shaders/tonemap.frag:37-70), in f32 like the shader:
+ * colour * exposure, ACESFitted (input matrix, RRTAndODTFit, output matrix, clamp), vignette 1 - distance(uv, 0.5)
+ * at the fragment centre, uv.y flipped. out row 0 = top of the screen, alpha 1. */
+static float oracle_aces_fit(float v) {
+    float a = v * (v + 0.0245786f) - 0.000090537f;
+    float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    return a / b;
+}
+int oracle_display_transform(const float *rgba, uint32_t width, uint32_t height, float exposure, float *out) {
+    static const float in_m[3][3] = {{0.59719f, 0.35458f, 0.04823f}, {0.07600f, 0.90834f, 0.01566f}, {0.02840f, 0.13383f, 0.83777f}};
+    static const float out_m[3][3] = {{1.60475f, -0.53108f, -0.07367f}, {-0.10208f, 1.10813f, -0.00605f}, {-0.00327f, -0.07276f, 1.07602f}};
+    for (uint32_t j = 0; j < height; ++j) {
+        for (uint32_t i = 0; i < width; ++i) {
+            const float *px = rgba + ((size_t)(height - j - 1) * width + i) * 4;
+            float c[3] = {px[0] * exposure, px[1] * exposure, px[2] * exposure};
+            float t[3], f[3];
+            for (int k = 0; k < 3; ++k) t[k] = c[0] * in_m[k][0] + c[1] * in_m[k][1] + c[2] * in_m[k][2];
+            for (int k = 0; k < 3; ++k) f[k] = oracle_aces_fit(t[k]);
+            float u = ((float)i + 0.5f) / (float)width, v = 1.0f - ((float)j + 0.5f) / (float)height;
+            float du = u - 0.5f, dv = v - 0.5f;
+            float vignette = 1.0f - std::sqrt(du * du + dv * dv);
+            float *o = out + ((size_t)j * width + i) * 4;
+            for (int k = 0; k < 3; ++k) {
+                float x = f[0] * out_m[k][0] + f[1] * out_m[k][1] + f[2] * out_m[k][2];
+                x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+                o[k] = x * vignette;
+            }
+            o[3] = 1.0f;
+        }
+    }
+    return 0;
+}
+
 } /* extern "C" */

@@ -194,7 +194,7 @@ EXPORTS = [
     "pt_scene_material_dielectric", "pt_scene_sphere", "pt_scene_moving_sphere", "pt_scene_rect", "pt_scene_box",
     "pt_scene_flip_normals", "pt_scene_translate", "pt_scene_rotate_y", "pt_scene_constant_medium", "pt_scene_list",
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
-    "pt_tonemap_rgb8", "pt_abi_version",
+    "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_abi_version",
 ]
 
 _vp = C.c_void_p
@@ -251,6 +251,8 @@ _sig("pt_scene_set_lights", C.c_int, _vp, _i32p, C.c_int)
 _sig("pt_scene_bounding_box", C.c_int, _vp, C.c_int, C.c_double, C.c_double, _d3, _d3)
 _sig("pt_scene_flatten_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p, _i32p)
 _sig("pt_tonemap_rgb8", C.c_int, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8))
+_sig("pt_tonemap_device", C.c_int, _vp, C.POINTER(C.c_uint8), C.c_size_t)
+_sig("pt_display_transform", C.c_int, _vp, C.c_float, C.POINTER(C.c_float), C.c_size_t)
 _sig("pt_abi_version", C.c_uint32)
 
 
@@ -457,6 +459,19 @@ class Context:
             "pt_intersect_device",
         )
         return ms.value
+
+    def tonemap_rgb8(self):
+        """Reinhard + sqrt gamma + u8 of the context's image on the device, top row first (pt_tonemap_device)."""
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._check(lib.pt_tonemap_device(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size), "pt_tonemap_device")
+        return out
+
+    def display_transform(self, exposure=1.3):
+        """ACES-fitted display transform with exposure and vignette (pt_display_transform): f32 RGBA, top row first."""
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(lib.pt_display_transform(self._h, float(exposure), out.ctypes.data_as(C.POINTER(C.c_float)), out.size),
+                    "pt_display_transform")
+        return out
 
     def stats(self) -> Stats:
         s = Stats()

@@ -943,6 +943,65 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const doub
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// post kernels: PPM conversion and the display transform
+// ------------------------------------------------------------------------------------------------------------
+// reinhard_tonemap (src/trace.rs:236-242) + sqrt gamma + `as u8` (src/lib.rs:330-340), rows flipped as the PPM
+// writer does (src/lib.rs:617-630). f64 with IEEE division and sqrt, as on the host.
+__global__ __launch_bounds__(kBlock) void k_tonemap_rgb8(const float *image, uint32_t width, uint32_t height,
+                                                         uint8_t *out) {
+    const uint32_t n = width * height;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+        const uint32_t i = p % width, j = p / width;
+        const float *px = image + ((size_t)(height - j - 1) * width + i) * 4;
+        for (int c = 0; c < 3; ++c) {
+            const double colour = (double)px[c] * 1.5;
+            const double mapped = colour / (colour + 1.0);
+            const double scaled = 255.99 * sqrt(mapped);
+            uint8_t b; // Rust's `as u8` saturates and maps NaN to 0
+            if (!(scaled > 0.0)) b = 0;
+            else if (scaled >= 255.0) b = 255;
+            else b = (uint8_t)scaled;
+            out[(size_t)p * 3 + c] = b;
+        }
+    }
+}
+// assets/shaders/tonemap.frag:37-70, f32 like the shader. `v * M` with a column-major mat3 is a dot product of v
+// with each constructor triple.
+__device__ __forceinline__ float aces_fit(float v) { // RRTAndODTFit, tonemap.frag:37-42
+    const float a = v * (v + 0.0245786f) - 0.000090537f;
+    const float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    return a / b;
+}
+__global__ __launch_bounds__(kBlock) void k_display_transform(const float *image, uint32_t width, uint32_t height,
+                                                              float exposure, float *out) {
+    const uint32_t n = width * height;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+        const uint32_t i = p % width, j = p / width; // j = 0 is the top of the screen
+        const float *px = image + ((size_t)(height - j - 1) * width + i) * 4;
+        const float r = px[0] * exposure, g = px[1] * exposure, b = px[2] * exposure;
+        const float ir = r * 0.59719f + g * 0.35458f + b * 0.04823f;
+        const float ig = r * 0.07600f + g * 0.90834f + b * 0.01566f;
+        const float ib = r * 0.02840f + g * 0.13383f + b * 0.83777f;
+        const float fr = aces_fit(ir), fg = aces_fit(ig), fb = aces_fit(ib);
+        float orr = fr * 1.60475f + fg * -0.53108f + fb * -0.07367f;
+        float org = fr * -0.10208f + fg * 1.10813f + fb * -0.00605f;
+        float orb = fr * -0.00327f + fg * -0.07276f + fb * 1.07602f;
+        orr = fminf(fmaxf(orr, 0.0f), 1.0f);
+        org = fminf(fmaxf(org, 0.0f), 1.0f);
+        orb = fminf(fmaxf(orb, 0.0f), 1.0f);
+        // uv of the fragment centre after the shader's flip; the distance is the same either way up
+        const float u = ((float)i + 0.5f) / (float)width, v = 1.0f - ((float)j + 0.5f) / (float)height;
+        const float du = u - 0.5f, dv = v - 0.5f;
+        const float vignette = 1.0f - sqrtf(du * du + dv * dv);
+        float *o = out + (size_t)p * 4;
+        o[0] = orr * vignette;
+        o[1] = org * vignette;
+        o[2] = orb * vignette;
+        o[3] = 1.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pt_intersect helpers
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_load_rays(const pt_ray *rays, uint32_t n, Queue q) {
@@ -1732,6 +1791,42 @@ int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double 
     hipLaunchKernelGGL(k_load_rays_soa, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, d_rays_soa, (uint32_t)n,
                        ctx->q[0]);
     return intersect_common(ctx, n, t_min, t_max, medium_seed, repeats, mean_ms_out);
+}
+
+int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes) {
+    if (!ctx || !rgb8_out) return PT_ERR_INVALID_ARG;
+    if (!ctx->d_image || ctx->width == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "no image: render first");
+    const size_t need = (size_t)ctx->width * ctx->height * 3;
+    if (n_bytes < need) return set_error(ctx, PT_ERR_INVALID_ARG, "rgb8_out too small");
+    (void)hipSetDevice(ctx->device);
+    uint8_t *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_out, need));
+    const uint32_t n = ctx->width * ctx->height;
+    hipLaunchKernelGGL(k_tonemap_rgb8, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image, ctx->width,
+                       ctx->height, d_out);
+    hipError_t e = hipMemcpyAsync(rgb8_out, d_out, need, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return set_error(ctx, PT_ERR_HIP, hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_floats) {
+    if (!ctx || !rgba_out) return PT_ERR_INVALID_ARG;
+    if (!ctx->d_image || ctx->width == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "no image: render first");
+    const size_t need = (size_t)ctx->width * ctx->height * 4;
+    if (n_floats < need) return set_error(ctx, PT_ERR_INVALID_ARG, "rgba_out too small");
+    (void)hipSetDevice(ctx->device);
+    float *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_out, need * sizeof(float)));
+    const uint32_t n = ctx->width * ctx->height;
+    hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image,
+                       ctx->width, ctx->height, exposure, d_out);
+    hipError_t e = hipMemcpyAsync(rgba_out, d_out, need * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return set_error(ctx, PT_ERR_HIP, hipGetErrorString(e));
+    return PT_OK;
 }
 
 int pt_stats_get(pt_ctx *ctx, pt_stats *out) {

@@ -72,6 +72,8 @@ lib.oracle_vec3_op.restype = C.c_int
 lib.oracle_vec3_op.argtypes = [C.c_int, _dp, _dp, _dp]
 lib.oracle_vec3_scalar.restype = C.c_double
 lib.oracle_vec3_scalar.argtypes = [C.c_int, _dp, _dp]
+lib.oracle_display_transform.restype = C.c_int
+lib.oracle_display_transform.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_float, _vp]
 lib.oracle_tonemap_rgb8.restype = C.c_int
 lib.oracle_tonemap_rgb8.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp]
 
@@ -177,6 +179,14 @@ def vec3_op(op, a, b=(0, 0, 0)):
 
 def vec3_scalar(op, a, b=(0, 0, 0)):
     return lib.oracle_vec3_scalar(op, _v(a), _v(b))
+
+
+def display_transform(rgba, exposure=1.3):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w, _ = rgba.shape
+    out = np.empty((h, w, 4), dtype=np.float32)
+    lib.oracle_display_transform(rgba.ctypes.data, w, h, float(exposure), out.ctypes.data)
+    return out
 
 
 def tonemap_rgb8(rgba):

@@ -219,3 +219,22 @@ def test_furnace_on_gpu(any_ctx):
     expected = a * e * sum(a ** k for k in range(depth + 1))
     assert st.segments >= 0.99 * st.paths * (depth + 1)
     assert np.nanmean(img[..., 0]) == pytest.approx(expected, rel=0.02)
+
+
+def test_post_kernels_match_oracle(gpu_ctx):
+    """pt_tonemap_device is bit-identical to the host conversion and to the oracle; pt_display_transform agrees with
+    the oracle's f32 restatement of the shader to 2e-6 (f32 arithmetic, contraction may differ)."""
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    gpu_ctx.upload(scene)
+    gpu_ctx.render(96, 64, 8, 10)
+    img = gpu_ctx.readback()
+    dev = gpu_ctx.tonemap_rgb8()
+    assert dev.shape == (64, 96, 3)
+    assert np.array_equal(dev, ptgpu.tonemap_rgb8(img))
+    assert np.array_equal(dev, ob.tonemap_rgb8(img))
+    for exposure in (1.3, 0.25):
+        got = gpu_ctx.display_transform(exposure)
+        ref = ob.display_transform(img, exposure)
+        assert got.shape == ref.shape == (64, 96, 4)
+        assert np.max(np.abs(got - ref)) <= 2e-6
+        assert np.all(got[..., 3] == 1.0)

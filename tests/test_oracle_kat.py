@@ -325,3 +325,30 @@ def test_golden_image_fixture():
     s = ptgpu.Scene.named("cornell_box", 1.0, seed=int(g["seed"]))
     img, _ = ob.render(s.desc(), s.camera, 32, 32, 8, 50, seed=int(g["seed"]), threads=4)
     assert np.allclose(img[..., :3], g["rgb"], rtol=1e-6, atol=1e-8, equal_nan=True)
+
+
+def test_display_transform_closed_forms():
+    """ACES-fitted display transform (assets/shaders/tonemap.frag:37-70): black stays black, the curve saturates
+    to 1, the vignette is 1 - distance from the screen centre, rows are flipped, alpha is 1."""
+    h, w = 6, 8
+    img = np.zeros((h, w, 4), dtype=np.float32)
+    out = ob.display_transform(img, 1.3)
+    assert np.all(out[..., :3] == 0.0) and np.all(out[..., 3] == 1.0)
+    img[..., :3] = 1000.0  # far into the shoulder: every channel clamps to 1, leaving the vignette alone
+    out = ob.display_transform(img, 1.3)
+    jj, ii = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    vig = 1.0 - np.sqrt(((ii + 0.5) / w - 0.5) ** 2 + ((jj + 0.5) / h - 0.5) ** 2)
+    assert np.allclose(out[..., 0], vig, atol=2e-6) and np.allclose(out[..., 2], vig, atol=2e-6)
+    # a mid grey through the published fit: x = 0.18 * exposure on all channels (the matrices' rows sum to 1)
+    img[..., :3] = 0.18
+    out = ob.display_transform(img, 1.0)
+    x = 0.18
+    fit = (x * (x + 0.0245786) - 0.000090537) / (x * (0.983729 * x + 0.4329510) + 0.238081)
+    rows = np.array([1.60475 - 0.53108 - 0.07367, -0.10208 + 1.10813 - 0.00605, -0.00327 - 0.07276 + 1.07602])
+    centre = out[h // 2, w // 2, :3] / vig[h // 2, w // 2]
+    assert np.allclose(centre, fit * rows, rtol=2e-4)
+    # row flip: the bottom scanline of the buffer ends up in the last output row
+    img[...] = 0.0
+    img[0, :, 0] = 0.5
+    out = ob.display_transform(img, 1.3)
+    assert np.all(out[-1, :, 0] > 0.0) and np.all(out[:-1, :, 0] == 0.0)
