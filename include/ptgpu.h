@@ -321,6 +321,46 @@ int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes);
  * of the screen (the shader's uv.y flip), alpha 1. */
 int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_floats);
 
+/* ---- realtime interaction (host side) ----
+ * Key bits of pt_user_input: the keys the reference's main loop and camera react to
+ * (src/camera.rs:121-189, src/lib.rs:425-451). */
+enum pt_key {
+    PT_KEY_W = 1 << 0, PT_KEY_S = 1 << 1, PT_KEY_A = 1 << 2, PT_KEY_D = 1 << 3, PT_KEY_E = 1 << 4, PT_KEY_Q = 1 << 5,
+    PT_KEY_RIGHT = 1 << 6, PT_KEY_LEFT = 1 << 7, PT_KEY_UP = 1 << 8, PT_KEY_DOWN = 1 << 9,
+    PT_KEY_T = 1 << 10, PT_KEY_R = 1 << 11, PT_KEY_O = 1 << 12, PT_KEY_P = 1 << 13, PT_KEY_B = 1 << 14
+};
+/* One frame of input::UserInput (src/input.rs:13-20): WASDQE and the app keys are read from keys_pressed, the arrow
+ * keys from keys_held, as the reference does. mouse_delta is (dx, -dy) as the reference stores it. */
+typedef struct pt_user_input {
+    uint32_t keys_pressed;
+    uint32_t keys_held;
+    float mouse_dx, mouse_dy;
+} pt_user_input;
+typedef struct pt_frame_info {
+    int32_t camera_moved;      /* Camera::update_from_input's result */
+    int32_t cleared;           /* accumulation was reset this frame (src/lib.rs:462-468) */
+    double exposure, numframes;/* TonemapperArgs.exposure_numframes_xx[0..1] after this frame */
+    double time0, time1;       /* SceneState.time0/1 after the advance of src/lib.rs:412-417 */
+    double sky_brightness;
+    int32_t disable_emissive;
+    uint32_t frame;            /* frames traced so far */
+    pt_camera camera;          /* the Camera::new parameters that reproduce the camera after this frame */
+} pt_frame_info;
+
+/* Replaces Camera::update_from_input followed by Camera::update (src/camera.rs:89-96,109-215) on a camera given by
+ * its Camera::new parameters; writes the parameters of the moved camera back. Returns 1 if it moved, 0 if not,
+ * negative pt_status on bad arguments. */
+int pt_camera_apply_input(pt_camera *cam, const pt_user_input *input, double frame_time);
+
+/* Replaces the realtime main loop body (src/lib.rs:406-478) minus window and present: see pt_session_frame. */
+typedef struct pt_session pt_session;
+int pt_session_new(pt_ctx *ctx, const pt_camera *cam, uint32_t width, uint32_t height, uint32_t max_depth,
+                   pt_session **out);
+void pt_session_free(pt_session *s);
+/* One iteration: time advance, T/R exposure keys, O/P/B scene keys, camera input, reset on move, then one
+ * progressive frame (mode realtime, spp 1). info may be NULL. */
+int pt_session_frame(pt_session *s, const pt_user_input *input, double frame_time, pt_frame_info *info);
+
 uint32_t pt_abi_version(void);
 
 #ifdef __cplusplus

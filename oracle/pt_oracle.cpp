@@ -1284,6 +1284,55 @@ int oracle_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint
     return 0;
 }
 
+/* Camera::update_from_input followed by Camera::update (camera.rs:89-96,109-215) on a camera held as plain numbers.
+ * cam = origin[3], look_at[3], vup[3] (in/out; the other Camera::new parameters do not change). keys are the bit
+ * masks of include/ptgpu.h (W S A D E Q = bits 0-5 read from `pressed`; Right Left Up Down = bits 6-9 read from
+ * `held`). Returns camera_moved. Written against the reference text, independently of the host library. */
+int oracle_camera_apply_input(double *cam, uint32_t pressed, uint32_t held, float mouse_dx, float mouse_dy,
+                              double frame_time) {
+    V3 origin = v3(cam[0], cam[1], cam[2]), look_at = v3(cam[3], cam[4], cam[5]), vup = v3(cam[6], cam[7], cam[8]);
+    /* the frame the camera holds since its last update() (camera.rs:30-32) */
+    V3 w = unit_vector(origin - look_at);
+    V3 u = unit_vector(cross(vup, w));
+    V3 v = cross(w, u);
+    const double CAM_SPEED = 40.0, MOUSE_LOOK_SPEED = 1.0;
+    bool moved = false;
+    struct Move { uint32_t bit; int axis; double sign; };
+    /* order of the `if`s in camera.rs:121-167: W S D A E Q; axis 0 = forward (-w), 1 = right (u), 2 = up (v) */
+    const Move moves[6] = {{1u << 0, 0, 1.0}, {1u << 1, 0, -1.0}, {1u << 3, 1, 1.0}, {1u << 2, 1, -1.0}, {1u << 4, 2, 1.0}, {1u << 5, 2, -1.0}};
+    for (const Move &m : moves) {
+        if (!(pressed & m.bit)) continue;
+        V3 axis = m.axis == 0 ? -w : (m.axis == 1 ? u : v);
+        V3 diff = axis * m.sign * CAM_SPEED * frame_time;
+        V3 new_origin = origin + diff;
+        look_at = look_at + (new_origin - origin); /* set_origin(.., true), camera.rs:77-83 */
+        origin = new_origin;
+        moved = true;
+    }
+    auto set_look_at = [&](V3 target) { /* camera.rs:98-107 with maintain_distance: scales the POSITION vector */
+        double look_at_dist = length(origin - look_at);
+        double new_look_at_dist = length(origin - target);
+        look_at = target * (look_at_dist / new_look_at_dist);
+    };
+    const Move looks[4] = {{1u << 6, 1, 1.0}, {1u << 7, 1, -1.0}, {1u << 8, 2, 1.0}, {1u << 9, 2, -1.0}};
+    for (const Move &m : looks) { /* camera.rs:169-192: Right Left Up Down */
+        if (!(held & m.bit)) continue;
+        V3 axis = m.axis == 1 ? u : v;
+        set_look_at(look_at + axis * m.sign * CAM_SPEED * frame_time);
+        moved = true;
+    }
+    if (mouse_dx != 0.0f || mouse_dy != 0.0f) { /* camera.rs:193-211 */
+        V3 target = look_at;
+        if (mouse_dx != 0.0f) target = target + u * MOUSE_LOOK_SPEED * frame_time * (double)mouse_dx;
+        if (mouse_dy != 0.0f) target = target + v * MOUSE_LOOK_SPEED * frame_time * (double)mouse_dy;
+        set_look_at(target);
+        moved = true;
+    }
+    cam[0] = origin.x; cam[1] = origin.y; cam[2] = origin.z;
+    cam[3] = look_at.x; cam[4] = look_at.y; cam[5] = look_at.z;
+    return moved ? 1 : 0;
+}
+
 /* The display transform of the rendy tonemap pass (assets/shaders/tonemap.frag:37-70), in f32 like the shader:
  * colour * exposure, ACESFitted (input matrix, RRTAndODTFit, output matrix, clamp), vignette 1 - distance(uv, 0.5)
  * at the fragment centre, uv.y flipped. out row 0 = top of the screen, alpha 1. */

@@ -127,6 +127,31 @@ class Camera(C.Structure):
     ]
 
 
+# key bits of UserInput (enum pt_key)
+PT_KEY_W, PT_KEY_S, PT_KEY_A, PT_KEY_D, PT_KEY_E, PT_KEY_Q = (1 << k for k in range(6))
+PT_KEY_RIGHT, PT_KEY_LEFT, PT_KEY_UP, PT_KEY_DOWN = (1 << k for k in range(6, 10))
+PT_KEY_T, PT_KEY_R, PT_KEY_O, PT_KEY_P, PT_KEY_B = (1 << k for k in range(10, 15))
+
+
+class UserInput(C.Structure):
+    _fields_ = [("keys_pressed", C.c_uint32), ("keys_held", C.c_uint32), ("mouse_dx", C.c_float), ("mouse_dy", C.c_float)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [
+        ("camera_moved", C.c_int32),
+        ("cleared", C.c_int32),
+        ("exposure", C.c_double),
+        ("numframes", C.c_double),
+        ("time0", C.c_double),
+        ("time1", C.c_double),
+        ("sky_brightness", C.c_double),
+        ("disable_emissive", C.c_int32),
+        ("frame", C.c_uint32),
+        ("camera", Camera),
+    ]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -194,7 +219,8 @@ EXPORTS = [
     "pt_scene_material_dielectric", "pt_scene_sphere", "pt_scene_moving_sphere", "pt_scene_rect", "pt_scene_box",
     "pt_scene_flip_normals", "pt_scene_translate", "pt_scene_rotate_y", "pt_scene_constant_medium", "pt_scene_list",
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
-    "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_abi_version",
+    "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
+    "pt_session_free", "pt_session_frame", "pt_abi_version",
 ]
 
 _vp = C.c_void_p
@@ -253,6 +279,10 @@ _sig("pt_scene_flatten_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p
 _sig("pt_tonemap_rgb8", C.c_int, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8))
 _sig("pt_tonemap_device", C.c_int, _vp, C.POINTER(C.c_uint8), C.c_size_t)
 _sig("pt_display_transform", C.c_int, _vp, C.c_float, C.POINTER(C.c_float), C.c_size_t)
+_sig("pt_camera_apply_input", C.c_int, C.POINTER(Camera), C.POINTER(UserInput), C.c_double)
+_sig("pt_session_new", C.c_int, _vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp))
+_sig("pt_session_free", None, _vp)
+_sig("pt_session_frame", C.c_int, _vp, C.POINTER(UserInput), C.c_double, C.POINTER(FrameInfo))
 _sig("pt_abi_version", C.c_uint32)
 
 
@@ -480,6 +510,48 @@ class Context:
 
     def stats_reset(self):
         self._check(lib.pt_stats_reset(self._h), "pt_stats_reset")
+
+
+def copy_camera(cam: Camera) -> Camera:
+    out = Camera()
+    C.memmove(C.byref(out), C.byref(cam), C.sizeof(Camera))
+    return out
+
+
+def camera_apply_input(cam: Camera, keys_pressed=0, keys_held=0, mouse=(0.0, 0.0), frame_time=1.0 / 60.0):
+    """Camera::update_from_input + update on a copy of `cam`; returns (moved, new camera)."""
+    out = copy_camera(cam)
+    ui = UserInput(keys_pressed, keys_held, mouse[0], mouse[1])
+    rc = lib.pt_camera_apply_input(C.byref(out), C.byref(ui), float(frame_time))
+    if rc < 0:
+        raise PtError(rc, "pt_camera_apply_input")
+    return bool(rc), out
+
+
+class Session:
+    """Headless replay of the realtime main loop (pt_session_*): one call to frame() per displayed frame."""
+
+    def __init__(self, ctx: "Context", camera: Camera, width, height, max_depth=10):
+        self._ctx = ctx
+        self._h = _vp()
+        rc = lib.pt_session_new(ctx._h, C.byref(camera), width, height, max_depth, C.byref(self._h))
+        if rc != PT_OK:
+            raise PtError(rc, "pt_session_new")
+        ctx.width, ctx.height = width, height
+
+    def frame(self, keys_pressed=0, keys_held=0, mouse=(0.0, 0.0), frame_time=1.0 / 60.0) -> FrameInfo:
+        ui = UserInput(keys_pressed, keys_held, mouse[0], mouse[1])
+        info = FrameInfo()
+        self._ctx._check(lib.pt_session_frame(self._h, C.byref(ui), float(frame_time), C.byref(info)), "pt_session_frame")
+        return info
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.pt_session_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def tonemap_rgb8(rgba):

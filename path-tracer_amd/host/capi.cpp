@@ -176,6 +176,34 @@ int pt_scene_bounding_box(const pt_scene *s, int node, double t0, double t1, dou
 }
 
 // reinhard_tonemap (src/trace.rs:236-242), gamma + `as u8` (src/lib.rs:330-340), PPM row flip (src/lib.rs:617-630)
+int pt_camera_apply_input(pt_camera *c, const pt_user_input *input, double frame_time) {
+    if (!c || !input) return PT_ERR_INVALID_ARG;
+    ptgpu::Camera cam(ptgpu::Vec3{c->origin[0], c->origin[1], c->origin[2]},
+                      ptgpu::Vec3{c->look_at[0], c->look_at[1], c->look_at[2]},
+                      ptgpu::Vec3{c->vup[0], c->vup[1], c->vup[2]}, c->vfov, c->aspect, c->aperture, c->focus_dist,
+                      c->time0, c->time1);
+    const bool moved = cam.update_from_input(*input, frame_time);
+    if (moved) cam.update();
+    *c = cam.params();
+    return moved ? 1 : 0;
+}
+
+struct pt_session {
+    ptgpu::RealtimeSession session;
+    pt_session(pt_ctx *ctx, const pt_camera &cam, uint32_t w, uint32_t h, uint32_t d) : session(ctx, cam, w, h, d) {}
+};
+int pt_session_new(pt_ctx *ctx, const pt_camera *cam, uint32_t width, uint32_t height, uint32_t max_depth,
+                   pt_session **out) {
+    if (!ctx || !cam || !out || width == 0 || height == 0) return PT_ERR_INVALID_ARG;
+    *out = new (std::nothrow) pt_session(ctx, *cam, width, height, max_depth);
+    return *out ? PT_OK : PT_ERR_OUT_OF_MEMORY;
+}
+void pt_session_free(pt_session *s) { delete s; }
+int pt_session_frame(pt_session *s, const pt_user_input *input, double frame_time, pt_frame_info *info) {
+    if (!s || !input) return PT_ERR_INVALID_ARG;
+    return s->session.frame(*input, frame_time, info);
+}
+
 int pt_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8_out) {
     if (!rgba || !rgb8_out) return PT_ERR_INVALID_ARG;
     const double exposure = 1.5;

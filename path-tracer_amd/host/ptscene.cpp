@@ -543,6 +543,40 @@ void Camera::set_look_at(Vec3 look_at, bool maintain_distance) { // camera.rs:98
     }
     look_at_ = look_at;
 }
+bool Camera::update_from_input(const pt_user_input &in, double frame_time) { // camera.rs:109-215
+    const double CAM_SPEED = 40.0;
+    const double MOUSE_LOOK_SPEED = 1.0;
+    bool camera_moved = false;
+    auto pressed = [&](uint32_t k) { return (in.keys_pressed & k) != 0; };
+    auto held = [&](uint32_t k) { return (in.keys_held & k) != 0; };
+    auto move = [&](Vec3 axis, double sign) { // camera.rs:121-167
+        Vec3 diff = axis * sign * CAM_SPEED * frame_time;
+        set_origin(get_origin() + diff, true);
+        camera_moved = true;
+    };
+    if (pressed(PT_KEY_W)) move(get_forward(), 1.0);
+    if (pressed(PT_KEY_S)) move(get_forward(), -1.0);
+    if (pressed(PT_KEY_D)) move(get_right(), 1.0);
+    if (pressed(PT_KEY_A)) move(get_right(), -1.0);
+    if (pressed(PT_KEY_E)) move(get_up(), 1.0);
+    if (pressed(PT_KEY_Q)) move(get_up(), -1.0);
+    auto look = [&](Vec3 axis, double sign) { // camera.rs:169-192
+        set_look_at(get_look_at() + axis * sign * CAM_SPEED * frame_time, true);
+        camera_moved = true;
+    };
+    if (held(PT_KEY_RIGHT)) look(get_right(), 1.0);
+    if (held(PT_KEY_LEFT)) look(get_right(), -1.0);
+    if (held(PT_KEY_UP)) look(get_up(), 1.0);
+    if (held(PT_KEY_DOWN)) look(get_up(), -1.0);
+    if (in.mouse_dx != 0.0f || in.mouse_dy != 0.0f) { // camera.rs:193-211
+        Vec3 cam_look_at = get_look_at();
+        if (in.mouse_dx != 0.0f) cam_look_at = cam_look_at + get_right() * MOUSE_LOOK_SPEED * frame_time * (double)in.mouse_dx;
+        if (in.mouse_dy != 0.0f) cam_look_at = cam_look_at + get_up() * MOUSE_LOOK_SPEED * frame_time * (double)in.mouse_dy;
+        set_look_at(cam_look_at, true);
+        camera_moved = true;
+    }
+    return camera_moved;
+}
 pt_camera Camera::params() const {
     pt_camera c;
     c.origin[0] = origin_.x; c.origin[1] = origin_.y; c.origin[2] = origin_.z;
@@ -555,6 +589,73 @@ pt_camera Camera::params() const {
     c.time0 = time0_;
     c.time1 = time1_;
     return c;
+}
+
+// ------------------------------------------------------------------ realtime session
+RealtimeSession::RealtimeSession(pt_ctx *ctx, const pt_camera &c, uint32_t width, uint32_t height, uint32_t max_depth)
+    : ctx_(ctx),
+      cam_(Vec3{c.origin[0], c.origin[1], c.origin[2]}, Vec3{c.look_at[0], c.look_at[1], c.look_at[2]},
+           Vec3{c.vup[0], c.vup[1], c.vup[2]}, c.vfov, c.aspect, c.aperture, c.focus_dist, c.time0, c.time1),
+      width_(width), height_(height), max_depth_(max_depth) {}
+
+int RealtimeSession::frame(const pt_user_input &in, double frame_time, pt_frame_info *info) {
+    bool clear_scene = false;
+    time0_ = time1_; // lib.rs:412-417
+    time1_ += frame_time;
+    numframes_ += 1.0; // lib.rs:419
+    auto pressed = [&](uint32_t k) { return (in.keys_pressed & k) != 0; };
+    if (pressed(PT_KEY_T)) exposure_ += 0.1; // lib.rs:425-429
+    else if (pressed(PT_KEY_R)) exposure_ -= 0.1;
+    if (pressed(PT_KEY_O)) { // lib.rs:431-435
+        clear_scene = true;
+        sky_brightness_ = std::max(sky_brightness_ - 0.05, 0.0);
+    }
+    if (pressed(PT_KEY_P)) { // lib.rs:437-441
+        clear_scene = true;
+        sky_brightness_ += 0.05;
+    }
+    if (pressed(PT_KEY_B)) { // lib.rs:443-447
+        disable_emissive_ = !disable_emissive_;
+        clear_scene = true;
+    }
+    const bool camera_moved = cam_.update_from_input(in, frame_time); // lib.rs:456-460
+    int rc = PT_OK;
+    const bool cleared = camera_moved || clear_scene;
+    if (cleared) { // lib.rs:462-468
+        cam_.update();
+        rc = pt_accum_reset(ctx_);
+        numframes_ = 1.0;
+    }
+    const pt_camera params = cam_.params();
+    if (rc == PT_OK && (cleared || frame_counter_ == 0)) rc = pt_camera_set(ctx_, &params);
+    if (rc == PT_OK) { // lib.rs:475-478: dispatch the tile jobs and wait; one job covers the image here
+        pt_render_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.struct_size = sizeof(a);
+        a.width = width_;
+        a.height = height_;
+        a.x1 = width_;
+        a.y1 = height_;
+        a.spp = 1;
+        a.max_depth = max_depth_;
+        a.mode = PT_MODE_REALTIME;
+        a.frame = frame_counter_;
+        rc = pt_render(ctx_, &a);
+    }
+    if (rc == PT_OK) frame_counter_ += 1;
+    if (info) {
+        info->camera_moved = camera_moved ? 1 : 0;
+        info->cleared = cleared ? 1 : 0;
+        info->exposure = exposure_;
+        info->numframes = numframes_;
+        info->time0 = time0_;
+        info->time1 = time1_;
+        info->sky_brightness = sky_brightness_;
+        info->disable_emissive = disable_emissive_ ? 1 : 0;
+        info->frame = frame_counter_;
+        info->camera = params;
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------ Config

@@ -177,6 +177,9 @@ class Camera {
     void set_origin(Vec3 origin, bool update_look_at);
     void set_look_at(Vec3 look_at, bool maintain_distance);
     void update();
+    // camera.rs:109-215: WASDQE move the origin (and the look-at with it), the arrow keys and the mouse move the
+    // look-at at constant distance. Returns camera_moved. `input` is a pt_user_input (include/ptgpu.h).
+    bool update_from_input(const pt_user_input &input, double frame_time);
     Vec3 lower_left_corner() const { return lower_left_corner_; }
     Vec3 horizontal() const { return horizontal_; }
     Vec3 vertical() const { return vertical_; }
@@ -228,6 +231,26 @@ class TraceSceneBatchJob {
     SceneState *state_;
     SceneOutput *output_;
     bool realtime_;
+};
+
+// The body of the realtime main loop (src/lib.rs:406-478) without the window: per frame it advances the scene time,
+// applies the exposure / sky / emissive keys and the camera input, clears the accumulation when something moved,
+// and traces one progressive frame (spp 1, depth 10) into the context's image.
+class RealtimeSession {
+  public:
+    RealtimeSession(pt_ctx *ctx, const pt_camera &camera, uint32_t width, uint32_t height, uint32_t max_depth);
+    int frame(const pt_user_input &input, double frame_time, pt_frame_info *info); // returns a pt_status
+    const Camera &camera() const { return cam_; }
+
+  private:
+    pt_ctx *ctx_;
+    Camera cam_;
+    uint32_t width_, height_, max_depth_;
+    double time0_ = 0.0, time1_ = 1.0; // SceneState.time0/1 (advanced every frame, read by nothing: lib.rs:415-416)
+    double exposure_ = 1.3, numframes_ = 1.0; // TonemapperArgs.exposure_numframes_xx, lib.rs:284-286
+    double sky_brightness_ = 0.0;             // stored and toggled, never read by color (trace.rs:49-50,227)
+    bool disable_emissive_ = false;
+    uint32_t frame_counter_ = 0;
 };
 
 // Tile grid of lib.rs:345-351, extended so edge tiles cover the whole image.

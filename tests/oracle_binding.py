@@ -72,6 +72,8 @@ lib.oracle_vec3_op.restype = C.c_int
 lib.oracle_vec3_op.argtypes = [C.c_int, _dp, _dp, _dp]
 lib.oracle_vec3_scalar.restype = C.c_double
 lib.oracle_vec3_scalar.argtypes = [C.c_int, _dp, _dp]
+lib.oracle_camera_apply_input.restype = C.c_int
+lib.oracle_camera_apply_input.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_double]
 lib.oracle_display_transform.restype = C.c_int
 lib.oracle_display_transform.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_float, _vp]
 lib.oracle_tonemap_rgb8.restype = C.c_int
@@ -179,6 +181,13 @@ def vec3_op(op, a, b=(0, 0, 0)):
 
 def vec3_scalar(op, a, b=(0, 0, 0)):
     return lib.oracle_vec3_scalar(op, _v(a), _v(b))
+
+
+def camera_apply_input(camera, keys_pressed=0, keys_held=0, mouse=(0.0, 0.0), frame_time=1.0 / 60.0):
+    """Returns (moved, origin, look_at) after update_from_input + update, from the oracle's restatement."""
+    cam = np.array(list(camera.origin) + list(camera.look_at) + list(camera.vup), dtype=np.float64)
+    moved = lib.oracle_camera_apply_input(cam.ctypes.data, keys_pressed, keys_held, mouse[0], mouse[1], frame_time)
+    return bool(moved), cam[0:3].copy(), cam[3:6].copy()
 
 
 def display_transform(rgba, exposure=1.3):

@@ -238,3 +238,51 @@ def test_post_kernels_match_oracle(gpu_ctx):
         assert got.shape == ref.shape == (64, 96, 4)
         assert np.max(np.abs(got - ref)) <= 2e-6
         assert np.all(got[..., 3] == 1.0)
+
+
+def test_realtime_session_replay(gpu_ctx):
+    """Headless replay of the realtime main loop (src/lib.rs:406-478): idle frames accumulate, a camera move clears
+    the accumulation and restarts the frame count, the app keys change exposure / sky / emissive state, and the
+    image after the script equals a fresh context that traced the same frames with the moved camera."""
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    gpu_ctx.upload(scene)
+    gpu_ctx.reset()
+    W = H = 64
+    dt = 1.0 / 60.0
+    ses = ptgpu.Session(gpu_ctx, scene.camera, W, H, max_depth=10)
+    for k in range(5):
+        info = ses.frame(frame_time=dt)
+        assert not info.camera_moved and not info.cleared
+        assert info.numframes == 2.0 + k and info.frame == k + 1
+    assert info.time0 == pytest.approx(1.0 + 4 * dt) and info.time1 == pytest.approx(1.0 + 5 * dt)
+    before = gpu_ctx.readback()
+    info = ses.frame(keys_pressed=ptgpu.PT_KEY_W | ptgpu.PT_KEY_D, frame_time=dt)
+    assert info.camera_moved and info.cleared and info.numframes == 1.0
+    moved_ref, o_ref, la_ref = ob.camera_apply_input(scene.camera, ptgpu.PT_KEY_W | ptgpu.PT_KEY_D, 0, (0.0, 0.0), dt)
+    assert moved_ref and list(info.camera.origin) == list(o_ref) and list(info.camera.look_at) == list(la_ref)
+    for k in range(3):
+        info = ses.frame(frame_time=dt)
+        assert not info.cleared and info.numframes == 2.0 + k
+    after = gpu_ctx.readback()
+    assert not np.array_equal(before, after)
+    # the same four frames (indices 5..8) on a fresh accumulation with the moved camera
+    ctx2 = ptgpu.Context(device=0, seed=gpu_ctx.seed)
+    ctx2.upload(scene)
+    ctx2.set_camera(info.camera)
+    for f in range(5, 9):
+        ctx2.render(W, H, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=f)
+    assert np.array_equal(ctx2.readback(), after, equal_nan=True)
+    ctx2.close()
+    # app keys: T / R exposure (lib.rs:425-429), O / P sky brightness with a floor of 0, B emissive toggle; O, P, B clear
+    info = ses.frame(keys_pressed=ptgpu.PT_KEY_T, frame_time=dt)
+    assert info.exposure == pytest.approx(1.4) and not info.cleared
+    info = ses.frame(keys_pressed=ptgpu.PT_KEY_R, frame_time=dt)
+    assert info.exposure == pytest.approx(1.3)
+    info = ses.frame(keys_pressed=ptgpu.PT_KEY_O, frame_time=dt)
+    assert info.cleared and info.sky_brightness == 0.0 and info.numframes == 1.0
+    info = ses.frame(keys_pressed=ptgpu.PT_KEY_P | ptgpu.PT_KEY_B, frame_time=dt)
+    assert info.cleared and info.sky_brightness == pytest.approx(0.05) and info.disable_emissive == 1
+    # the display transform with the session's exposure is what the present pass would show
+    shown = gpu_ctx.display_transform(info.exposure)
+    assert shown.shape == (H, W, 4) and np.isfinite(shown).all()
+    ses.close()

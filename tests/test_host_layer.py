@@ -201,3 +201,45 @@ def test_stripe_partition_covers_the_image_once():
             assert rows == list(range(height))
             counts = [len(tiles.stripes_for(r, world, height)) for r in range(world)]
             assert max(counts) - min(counts) <= 1
+
+
+def test_camera_input_matches_oracle_and_closed_forms():
+    """Camera::update_from_input (camera.rs:109-215): WASDQE translate origin and look-at together by 40 units/s along
+    the camera axes; arrows and mouse move the look-at and rescale its POSITION vector to keep the distance
+    (camera.rs:98-107). The host mirror and the oracle's restatement agree bit for bit over a random script."""
+    cam = ptgpu.make_camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    dt = 1.0 / 60.0
+    moved, c2 = ptgpu.camera_apply_input(cam, keys_pressed=ptgpu.PT_KEY_W, frame_time=dt)
+    assert moved
+    # forward = -w = unit(look_at - origin) = +z here
+    assert np.allclose(list(c2.origin), (278, 278, -800 + 40 * dt), atol=1e-12)
+    assert np.allclose(list(c2.look_at), (278, 278, 40 * dt), atol=1e-12)
+    moved, c3 = ptgpu.camera_apply_input(cam, frame_time=dt)
+    assert not moved and list(c3.origin) == list(cam.origin) and list(c3.look_at) == list(cam.look_at)
+    # W and S in one frame cancel (both are applied, in that order)
+    moved, c4 = ptgpu.camera_apply_input(cam, keys_pressed=ptgpu.PT_KEY_W | ptgpu.PT_KEY_S, frame_time=dt)
+    assert moved and np.allclose(list(c4.origin), list(cam.origin), atol=1e-12)
+    # right arrow: target = look_at + u * 40 dt, then scaled by |o - look_at| / |o - target| about the WORLD origin
+    moved, c5 = ptgpu.camera_apply_input(cam, keys_held=ptgpu.PT_KEY_RIGHT, frame_time=dt)
+    o, la = np.array(list(cam.origin)), np.array(list(cam.look_at))
+    w = (o - la) / np.linalg.norm(o - la)
+    u = np.cross((0, 1, 0), w)
+    u /= np.linalg.norm(u)
+    target = la + u * 40 * dt
+    expect = target * (np.linalg.norm(o - la) / np.linalg.norm(o - target))
+    assert moved and np.allclose(list(c5.look_at), expect, atol=1e-10) and list(c5.origin) == list(cam.origin)
+    # arrows are read from keys_held, WASD from keys_pressed
+    assert not ptgpu.camera_apply_input(cam, keys_pressed=ptgpu.PT_KEY_RIGHT, frame_time=dt)[0]
+    assert not ptgpu.camera_apply_input(cam, keys_held=ptgpu.PT_KEY_W, frame_time=dt)[0]
+
+    rng = np.random.default_rng(7)
+    c = cam
+    for step in range(200):
+        pressed = int(rng.integers(0, 1 << 6)) if rng.random() < 0.7 else 0
+        held = int(rng.integers(0, 1 << 4)) << 6 if rng.random() < 0.5 else 0
+        mouse = (float(rng.normal() * 5), float(rng.normal() * 5)) if rng.random() < 0.4 else (0.0, 0.0)
+        ft = float(rng.uniform(0.002, 0.05))
+        m_ref, o_ref, la_ref = ob.camera_apply_input(c, pressed, held, mouse, ft)
+        m_got, c = ptgpu.camera_apply_input(c, pressed, held, mouse, ft)
+        assert m_got == m_ref
+        assert list(c.origin) == list(o_ref) and list(c.look_at) == list(la_ref), step
