@@ -199,8 +199,15 @@ typedef struct pt_render_args {
     uint32_t max_depth;       /* Config.max_depth (src/lib.rs:109-123) */
     uint32_t mode;            /* pt_render_mode */
     uint32_t frame;           /* dispatch number; salts the RNG so successive realtime frames differ */
-    uint32_t reserved;
+    uint32_t flags;           /* pt_render_flags */
 } pt_render_args;
+
+/* PT_RENDER_BOOK_SEMANTICS: Isotropic scatters as in the book instead of as in the reference. The reference's
+ * Isotropic has no scattering_pdf (0 by the trait default, src/material.rs:142-144) and a DummyPDF that generates the
+ * zero vector (439-445), so every medium scatter yields 0 or NaN. With this flag its pdf is the uniform sphere:
+ * value 1/(4 pi) (the unused unit_sphere_pdf, src/material.rs:46-48), direction = the unit vector scatter() already
+ * draws (349), scattering_pdf 1/(4 pi). Same number of RNG draws either way. */
+enum pt_render_flags { PT_RENDER_BOOK_SEMANTICS = 1 };
 
 typedef struct pt_stats {
     uint64_t paths;            /* paths traced since the last pt_stats_reset */

@@ -166,6 +166,7 @@ struct Ctx {
     uint32_t depth; /* bounce depth of the segment being intersected */
     Counters *c;
     bool counting;  /* false while evaluating pdf_value re-intersections */
+    bool book = false; /* PT_RENDER_BOOK_SEMANTICS: Isotropic with the uniform-sphere pdf */
 };
 
 /* ----------------------------------------------------------- geometry -- */
@@ -669,7 +670,7 @@ inline double schlick(double cosine, double ref_idx) { /* material.rs:66-70 */
     return r0 + (1.0 - r0) * std::pow(1.0 - cosine, 5.0);
 }
 
-enum PdfKind { PDF_DUMMY = 0, PDF_COSINE = 1 };
+enum PdfKind { PDF_DUMMY = 0, PDF_COSINE = 1, PDF_SPHERE = 2 /* book semantics only */ };
 struct Scatter { /* material.rs:133-138 */
     Ray specular_ray;
     bool is_specular;
@@ -747,7 +748,7 @@ bool scatter(Ctx &cx, int mat, const Ray &r_in, const HitRec &rec, Scatter &out)
         out.specular_ray = Ray{rec.p, random_in_unit_sphere(cx.rng), r_in.time};
         out.albedo = texture_value(cx.s, m.texture, rec.u, rec.v, rec.p);
         out.is_specular = false;
-        out.pdf = PDF_DUMMY;
+        out.pdf = cx.book ? PDF_SPHERE : PDF_DUMMY;
         return true;
     }
     default: /* DUMMY, DIFFUSE_LIGHT */
@@ -756,7 +757,8 @@ bool scatter(Ctx &cx, int mat, const Ray &r_in, const HitRec &rec, Scatter &out)
 }
 
 /* Material::scattering_pdf (material.rs:142-144 default, 268-275) */
-double scattering_pdf(const pt_scene_desc *s, int mat, const HitRec &rec, const Ray &scattered) {
+double scattering_pdf(const pt_scene_desc *s, int mat, const HitRec &rec, const Ray &scattered, bool book) {
+    if (book && s->materials[mat].kind == PT_M_ISOTROPIC) return 1.0 / (4.0 * PI); /* unit_sphere_pdf, material.rs:46-48 */
     if (s->materials[mat].kind == PT_M_LAMBERTIAN) {
         double cosine = dot(rec.n, unit_vector(scattered.d));
         if (cosine < 0.0) return 0.0;
@@ -772,10 +774,12 @@ inline double scatter_pdf_value(const Scatter &sc, V3 direction) {
         if (cosine > 0.0) return cosine * FRAC_1_PI;
         return 0.0;
     }
+    if (sc.pdf == PDF_SPHERE) return 1.0 / (4.0 * PI);
     return 0.0;
 }
 inline V3 scatter_pdf_generate(Ctx &cx, const Scatter &sc) {
     if (sc.pdf == PDF_COSINE) return onb_local(sc.uvw, random_cosine_direction(cx.rng));
+    if (sc.pdf == PDF_SPHERE) return sc.specular_ray.d; /* the unit vector Isotropic::scatter drew (material.rs:349) */
     return v3(0, 0, 0);
 }
 
@@ -803,7 +807,7 @@ V3 color(Ctx &cx, const Ray &r, int depth, int max_depth) {
                     Ray scattered{rec.p, dir, r.time};
                     double pdf_val = 0.5 * lights_pdf_value(cx, rec.p, scattered.d) +
                                      0.5 * scatter_pdf_value(sc, scattered.d);
-                    double spdf = scattering_pdf(cx.s, rec.mat, rec, scattered);
+                    double spdf = scattering_pdf(cx.s, rec.mat, rec, scattered, cx.book);
                     V3 colour = sc.albedo * spdf * color(cx, scattered, depth + 1, max_depth) / pdf_val;
                     return colour + emissive;
                 }
@@ -885,6 +889,7 @@ void trace_tile(const RenderJob &job, uint32_t x0, uint32_t y0, uint32_t x1, uin
                 Ctx cx;
                 cx.s = job.s;
                 cx.pkey = path_key(job.seed, a.frame, pixel, s);
+                cx.book = (a.flags & PT_RENDER_BOOK_SEMANTICS) != 0;
                 cx.rng = Rng{cx.pkey, 0};
                 cx.depth = 0;
                 cx.c = &cnt;

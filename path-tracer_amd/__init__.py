@@ -36,6 +36,7 @@ PT_ERR_TOO_LARGE = -8
 
 PT_MODE_OFFLINE = 0
 PT_MODE_REALTIME = 1
+PT_RENDER_BOOK_SEMANTICS = 1
 PT_CFG_PROFILE_STAGES = 1
 PT_CFG_COUNT_TRAVERSAL = 2
 PT_CFG_EXACT = 4
@@ -175,7 +176,7 @@ class RenderArgs(C.Structure):
         ("max_depth", C.c_uint32),
         ("mode", C.c_uint32),
         ("frame", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("flags", C.c_uint32),
     ]
 
 
@@ -449,9 +450,9 @@ class Context:
     def set_camera(self, cam: Camera):
         self._check(lib.pt_camera_set(self._h, C.byref(cam)), "pt_camera_set")
 
-    def render(self, width, height, spp, max_depth, tile=None, mode=PT_MODE_OFFLINE, frame=0):
+    def render(self, width, height, spp, max_depth, tile=None, mode=PT_MODE_OFFLINE, frame=0, flags=0):
         x0, y0, x1, y1 = tile if tile is not None else (0, 0, width, height)
-        a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, 0)
+        a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags)
         self._check(lib.pt_render(self._h, C.byref(a)), "pt_render")
         self.width, self.height = width, height
 

@@ -97,6 +97,7 @@ struct PassParams {
     uint32_t max_depth;
     uint32_t mode;
     uint32_t first_pass, last_pass;
+    uint32_t flags;         // pt_render_flags
 };
 
 struct TraversalCounters {
@@ -680,7 +681,7 @@ template <bool X, bool NEED_UV, int FUSE>
 __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
                                                   uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   double *lx, double *ly, double *lz,
-                                                  uint32_t depth, uint32_t max_depth) {
+                                                  uint32_t depth, uint32_t max_depth, uint32_t flags) {
     __shared__ ShadeLds<(FUSE != 0) ? 1 : 0> S;
     uint32_t *lds = S.cnt;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -797,7 +798,15 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
                     } else if (lf.mat_kind == PT_M_LAMBERTIAN || lf.mat_kind == PT_M_ISOTROPIC) {
                         const bool lambert = lf.mat_kind == PT_M_LAMBERTIAN;
                         // scatter(): src/material.rs:289-301 (Lambertian), 347-351 (Isotropic draws a sphere sample it never uses)
-                        if (!lambert) (void)random_in_unit_sphere(g);
+                        // With PT_RENDER_BOOK_SEMANTICS that sample is the scattered direction and the pdf is the
+                        // uniform sphere's, 1/(4 pi) (unit_sphere_pdf, src/material.rs:46-48).
+                        const bool book = (flags & PT_RENDER_BOOK_SEMANTICS) != 0 && !lambert;
+                        D3 iso_dir = d3(0.0, 0.0, 0.0);
+                        if (!lambert) {
+                            const D3 sample = random_in_unit_sphere(g);
+                            if (book) iso_dir = sample;
+                        }
+                        const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
                         const D3 albedo = leaf_texture(sv, lf, rec);
                         add_radiance(lx, ly, lz, pid, beta * emissive);
                         if constexpr (X) {
@@ -806,16 +815,16 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
                             // MixturePDF::generate, src/material.rs:427-433
                             D3 dir;
                             if (g.next() < 0.5) dir = lights_random<X>(sv, g, rec.p);
-                            else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : d3(0.0, 0.0, 0.0);
+                            else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : iso_dir;
                             // MixturePDF::value, src/material.rs:424-426
                             const D3 unit_dir = M<X>::unit_vector(dir);
-                            double own = 0.0;
+                            double own = iso_pdf;
                             if (lambert) { // CosinePDF::value, src/material.rs:375-382
                                 double cosine = M<X>::dot(unit_dir, uvw.w);
                                 own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
                             }
                             const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir) + 0.5 * own;
-                            double spdf = 0.0;
+                            double spdf = iso_pdf;
                             if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
                                 double cosine = M<X>::dot(rec.n, unit_dir);
                                 spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
@@ -833,12 +842,12 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
                                 const double x = (double)sv.n_lights * g.next(); // HitableList::random, hitable.rs:74-77
                                 dir = light_random_fast(sv.lights[(int)x], g, rec.p);
                             } else {
-                                dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(g))) : d3(0.0, 0.0, 0.0);
+                                dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(g))) : iso_dir;
                             }
                             const F3 dirf = to_f3(dir);
                             const float len2 = dotf(dirf, dirf);
                             const F3 unit_dir = dirf * __builtin_amdgcn_rsqf(len2);
-                            float own = 0.0f, spdf = 0.0f;
+                            float own = (float)iso_pdf, spdf = (float)iso_pdf;
                             if (lambert) {
                                 const float cw = dotf(unit_dir, uvw.w);
                                 own = cw > 0.0f ? cw * 0.31830988618379067154f : 0.0f;
@@ -1106,6 +1115,7 @@ struct pt_ctx {
     void *d_ops_list = nullptr;
     int32_t n_list_ops = 0;
     bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
+    uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     void *d_ops_fused = nullptr;
     int32_t n_fused_ops = 0;
     std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
@@ -1272,7 +1282,7 @@ void launch_shade_xuf(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, u
     }
     hipLaunchKernelGGL((k_shade<X, UV, FUSE>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
                        ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, v, ctx->d_hit_t,
-                       ctx->d_hit_id, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth);
+                       ctx->d_hit_id, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth, ctx->render_flags);
 }
 // fused = trace inside the shade kernel (fast mode, box-free list, no transformed subtrees)
 void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth, bool fused) {
@@ -1644,6 +1654,7 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
     (void)hipSetDevice(ctx->device);
     int rc = ensure_image(ctx, a->width, a->height);
     if (rc != PT_OK) return rc;
+    ctx->render_flags = a->flags;
 
     const uint32_t tw = a->x1 - a->x0, th = a->y1 - a->y0;
     if (tw > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "tile row wider than the paths-in-flight budget");
@@ -1667,6 +1678,7 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
         pp.spp = a->spp;
         pp.max_depth = a->max_depth;
         pp.mode = a->mode;
+        pp.flags = a->flags;
         const uint32_t s_per_pass = std::max<uint32_t>(1, std::min<uint32_t>(a->spp, ctx->capacity / pp.cpix));
         for (uint32_t s0 = 0; s0 < a->spp; s0 += s_per_pass) {
             pp.s_base = s0;

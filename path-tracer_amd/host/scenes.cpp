@@ -169,7 +169,7 @@ pt_camera cornell_box(Scene &s, double aspect) {
 }
 
 // lib.rs:894-988. book_semantics flips the light so that it faces the room (the reference leaves it unflipped,
-// so its DiffuseLight never emits downwards).
+// so its DiffuseLight never emits downwards); the caller then also samples that light alone.
 pt_camera cornell_smoke(Scene &s, double aspect, bool book_semantics) {
     MaterialBuilder material_builder(s);
     Material red_mat = material_builder.with_texture(s.constant_texture(Vec3(0.65, 0.05, 0.05))).lambertian();
@@ -326,7 +326,15 @@ bool build_named_scene(const std::string &name, double aspect, uint64_t seed, in
         error = "unknown scene name: " + name;
         return false;
     }
-    s.set_default_lights(); // trace.rs:123-128: the same two light shapes for every scene
+    if (name == "cornell_smoke" && param == 1) {
+        // book variant: importance-sample this scene's own light only. The reference's hard-coded pair
+        // (trace.rs:123-128) includes a sphere at (190,90,190) that the smoke box overlaps, and Sphere::pdf_value
+        // from inside it is sqrt of a negative number (sphere.rs:92-94).
+        Material dummy = s.dummy_material();
+        s.set_lights({s.rect(113.0, 443.0, 127.0, 432.0, 554.0, Axis::Y, dummy)});
+    } else {
+        s.set_default_lights(); // trace.rs:123-128: the same two light shapes for every scene
+    }
     if (!s.error().empty()) {
         error = s.error();
         return false;

@@ -95,9 +95,9 @@ def intersect(desc, rays, t_min=0.001, t_max=F64_MAX, medium_seed=0):
     return hits, st
 
 
-def render(desc, camera, width, height, spp, max_depth, seed=0x5EED0001, tile=None, mode=0, frame=0, threads=0, image=None, counts=None):
+def render(desc, camera, width, height, spp, max_depth, seed=0x5EED0001, tile=None, mode=0, frame=0, threads=0, image=None, counts=None, flags=0):
     x0, y0, x1, y1 = tile if tile is not None else (0, 0, width, height)
-    a = ptgpu.RenderArgs(C.sizeof(ptgpu.RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, 0)
+    a = ptgpu.RenderArgs(C.sizeof(ptgpu.RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags)
     if image is None:
         image = np.zeros((height, width, 4), dtype=np.float32)
     st = OracleStats()

@@ -286,3 +286,25 @@ def test_realtime_session_replay(gpu_ctx):
     shown = gpu_ctx.display_transform(info.exposure)
     assert shown.shape == (H, W, 4) and np.isfinite(shown).all()
     ses.close()
+
+
+def test_book_semantics_smoke_scene(any_ctx):
+    """PT_RENDER_BOOK_SEMANTICS: Isotropic scatters with the uniform-sphere pdf (value and scattering_pdf 1/(4 pi),
+    direction = the unit vector scatter() draws). cornell_smoke with the light flipped towards the room then gives
+    a finite image, identical to the oracle's under the same flag; without the flag the reference's NaNs return."""
+    ctx, exact = any_ctx
+    scene = ptgpu.Scene.named("cornell_smoke", 1.0, param=1)
+    ctx.upload(scene)
+    w = h = 48
+    ctx.render(w, h, 8, 12, flags=ptgpu.PT_RENDER_BOOK_SEMANTICS)
+    got = ctx.readback()[..., :3].astype(np.float64)
+    ref, _ = ob.render(scene.desc(), scene.camera, w, h, 8, 12, seed=ctx.seed, threads=4, flags=ptgpu.PT_RENDER_BOOK_SEMANTICS)
+    ref = ref[..., :3].astype(np.float64)
+    assert np.isfinite(ref).all() and np.isfinite(got).all()
+    assert ref.mean() > 0.01  # the smoke volumes now carry light
+    close = np.isclose(got, ref, rtol=1e-5 if exact else 2e-3, atol=1e-7 if exact else 1e-5)
+    assert close.mean() >= (0.999 if exact else 0.97)
+    rmse = np.sqrt(np.mean((got - ref) ** 2)) / max(np.sqrt(np.mean(ref ** 2)), 1e-12)
+    assert rmse <= (1e-6 if exact else 0.05)
+    ctx.render(w, h, 8, 12)
+    assert np.isnan(ctx.readback()[..., :3]).any()  # reference semantics: 0 * x / 0 on medium scatters
