@@ -313,6 +313,12 @@ int pt_scene_bounding_box(const pt_scene *s, int node, double t0, double t1, dou
 int pt_scene_flatten_info(const pt_scene_desc *scene, int32_t *n_ops, int32_t *n_leaves, int32_t *n_xforms,
                           int32_t *max_frame_depth);
 
+/* Fast mode traces scenes that are not a short primitive list through a SAH tree over the same primitives, built on
+ * the host at upload (no reference counterpart: it stands in for walking BvhNode::from_list's tree, src/bvh.rs:13-99,
+ * and returns the same closest hit up to exact ties). This builds that tree for a scene and checks it on the host:
+ * every primitive in exactly one leaf, child boxes enclose their subtrees, depth within the traversal stack. */
+int pt_scene_accel_info(const pt_scene_desc *scene, int32_t *n_nodes, int32_t *n_prims, int32_t *depth);
+
 /* Reinhard(1.5) + sqrt gamma + u8 conversion with the row flip of the PPM writers
  * (src/trace.rs:236-242, src/lib.rs:330-340,613-640). rgb8_out is width*height*3, top row first. */
 int pt_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8_out);

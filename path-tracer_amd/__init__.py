@@ -221,7 +221,7 @@ EXPORTS = [
     "pt_scene_flip_normals", "pt_scene_translate", "pt_scene_rotate_y", "pt_scene_constant_medium", "pt_scene_list",
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
     "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
-    "pt_session_free", "pt_session_frame", "pt_abi_version",
+    "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_abi_version",
 ]
 
 _vp = C.c_void_p
@@ -284,6 +284,7 @@ _sig("pt_camera_apply_input", C.c_int, C.POINTER(Camera), C.POINTER(UserInput), 
 _sig("pt_session_new", C.c_int, _vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp))
 _sig("pt_session_free", None, _vp)
 _sig("pt_session_frame", C.c_int, _vp, C.POINTER(UserInput), C.c_double, C.POINTER(FrameInfo))
+_sig("pt_scene_accel_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p)
 _sig("pt_abi_version", C.c_uint32)
 
 
@@ -395,6 +396,15 @@ class Scene:
         if rc != PT_OK:
             raise PtError(rc, "bounding_box")
         return np.array(mn), np.array(mx)
+
+    def accel_info(self):
+        """Builds and verifies the fast-mode SAH tree on the host; returns node / primitive counts and depth."""
+        d = self.desc()
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = lib.pt_scene_accel_info(C.byref(d), C.byref(a), C.byref(b), C.byref(c))
+        if rc != PT_OK:
+            raise PtError(rc, "pt_scene_accel_info")
+        return {"n_nodes": a.value, "n_prims": b.value, "depth": c.value}
 
     def flatten_info(self):
         d = self.desc()

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "accel.h"
 #include "flatten.h"
 #include "pt_device.h"
 
@@ -609,6 +610,97 @@ __global__ __launch_bounds__(kBlock) void k_extend_list(Queue q, SceneView sv, E
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Fast-mode traversal of the SAH tree built at upload (accel.h): per-lane, nearer child first, the far child on a
+// per-lane stack in LDS. A node record holds the boxes of both children, so one 128-B fetch decides both.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool accel_box(const double *lo, const double *hi, D3 o, D3 inv, double t_min, double t_max,
+                                          double &t_near) {
+    const double x0 = (lo[0] - o.x) * inv.x, x1 = (hi[0] - o.x) * inv.x;
+    const double y0 = (lo[1] - o.y) * inv.y, y1 = (hi[1] - o.y) * inv.y;
+    const double z0 = (lo[2] - o.z) * inv.z, z1 = (hi[2] - o.z) * inv.z;
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), t_min));
+    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+
+template <bool MEDIA>
+__global__ __launch_bounds__(kBlock, 4) void k_extend_accel(Queue q, SceneView sv, const AccelNode *nodes,
+                                                         const DevOp *prims, ExtendArgs a) {
+    __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
+    const uint32_t n_virtual = ((max_shard_count(a.counts, a.sh.shards) + kBlock - 1) / kBlock) << a.sh.shift;
+    for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+        const uint32_t s_id = v & (a.sh.shards - 1);
+        const uint32_t local = (v >> a.sh.shift) * kBlock + threadIdx.x;
+        if (local >= shard_count(a.counts, s_id)) continue;
+        const uint32_t i = s_id * a.sh.shard_cap + local;
+        const D3 o = d3(q.ox(i), q.oy(i), q.oz(i));
+        const D3 d = d3(q.dx(i), q.dy(i), q.dz(i));
+        const double time = q.tm(i);
+        uint64_t pkey = 0;
+        if (MEDIA) pkey = (a.key_mode == 0) ? q.key(i) : intersect_key(a.medium_seed, i);
+        const D3 inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+        double closest = a.t_max;
+        int32_t best = -1;
+        // tests the primitives of a leaf child
+        auto leaf = [&](int32_t first, int32_t count) {
+            for (int32_t k = first; k < first + count; ++k) {
+                const DevOp op = prims[k];
+                double t = 0.0;
+                int sub = 0;
+                bool hit;
+                if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
+                    hit = medium_hit<false>(sv, op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t);
+                else hit = prim_hit<false>(sv, op, o, d, inv, time, a.t_min, closest, t, sub);
+                if (hit) {
+                    closest = t;
+                    best = op.leaf | (sub << 28);
+                }
+            }
+        };
+        int32_t node = 0;
+        int sp = 0;
+        for (;;) {
+            const AccelNode &n = nodes[node];
+            double t0, t1;
+            bool h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
+            bool h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
+            const int32_t c0 = n.child[0], c1 = n.child[1];
+            const int32_t k0 = n.count[0], k1 = n.count[1];
+            // leaf children are tested on the spot, nearer one first so that the farther may be skipped
+            if (h0 && h1 && c0 < 0 && c1 < 0 && t1 < t0) {
+                leaf(~c1, k1);
+                h1 = false;
+            }
+            if (h0 && c0 < 0) {
+                if (t0 <= closest) leaf(~c0, k0);
+                h0 = false;
+            }
+            if (h1 && c1 < 0) {
+                if (t1 <= closest) leaf(~c1, k1);
+                h1 = false;
+            }
+            h0 = h0 && t0 <= closest;
+            h1 = h1 && t1 <= closest;
+            if (h0 && h1) {
+                const bool first0 = t0 <= t1;
+                stack[sp++][threadIdx.x] = first0 ? c1 : c0;
+                node = first0 ? c0 : c1;
+            } else if (h0) {
+                node = c0;
+            } else if (h1) {
+                node = c1;
+            } else {
+                if (sp == 0) break;
+                node = stack[--sp][threadIdx.x];
+            }
+        }
+        a.hit_t[i] = closest;
+        a.hit_id[i] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // shade + compaction
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz, uint32_t pid, D3 c) {
@@ -1116,6 +1208,10 @@ struct pt_ctx {
     int32_t n_list_ops = 0;
     bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
+    bool use_accel = true;         // fast mode: SAH tree for scenes that are not a short list (PTGPU_ACCEL=0 disables)
+    bool accel_ok = false;
+    void *d_accel_nodes = nullptr, *d_accel_prims = nullptr;
+    int accel_depth = 0;
     void *d_ops_fused = nullptr;
     int32_t n_fused_ops = 0;
     std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
@@ -1246,7 +1342,10 @@ D3 hunit(D3 a) {
 
 template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
-    if (!X && !FRAMES && ctx->use_scan && ctx->scan_list && ctx->fuse_ok && ctx->fuse && a.counters == nullptr) {
+    if (!X && ctx->accel_ok && a.counters == nullptr) {
+        hipLaunchKernelGGL((k_extend_accel<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
+                           (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a);
+    } else if (!X && !FRAMES && ctx->use_scan && ctx->scan_list && ctx->fuse_ok && ctx->fuse && a.counters == nullptr) {
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_fused;
         v.n_traversal_ops = ctx->n_fused_ops;
@@ -1432,6 +1531,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (const char *e = std::getenv("PTGPU_SCAN_MAX_OPS")) ctx->scan_max_ops = (int)std::strtol(e, nullptr, 10);
     if (const char *e = std::getenv("PTGPU_LIST_MAX_LEAVES")) ctx->list_max_leaves = (int)std::strtol(e, nullptr, 10);
     if (const char *e = std::getenv("PTGPU_FUSE")) ctx->fuse = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("PTGPU_ACCEL")) ctx->use_accel = std::strtol(e, nullptr, 10) != 0;
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;
     if (const char *e = std::getenv("PTGPU_PROFILE_PERIOD")) {
@@ -1459,7 +1559,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
-                    ctx->d_ops_list, ctx->d_ops_fused,
+                    ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims,
                     ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1583,6 +1683,18 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
                 for (size_t k = n_list; k < list.size(); ++k) fl.push_back(list[k]); // sentinel + boundary ops
                 if ((rc = upload(ctx, &ctx->d_ops_fused, fl.data(), fl.size())) != PT_OK) return rc;
             }
+        }
+    }
+    // Everything else in fast mode is traced through a SAH tree over the same primitives (accel.h).
+    ctx->accel_ok = false;
+    if (!ctx->exact && !ctx->scan_list && ctx->use_accel) {
+        Accel acc;
+        std::string why;
+        if (build_accel(f, acc, why)) {
+            if ((rc = upload(ctx, &ctx->d_accel_nodes, acc.nodes.data(), acc.nodes.size())) != PT_OK) return rc;
+            if ((rc = upload(ctx, &ctx->d_accel_prims, acc.prims.data(), acc.prims.size())) != PT_OK) return rc;
+            ctx->accel_depth = acc.depth;
+            ctx->accel_ok = true;
         }
     }
     ctx->profile.clear();

@@ -243,3 +243,16 @@ def test_camera_input_matches_oracle_and_closed_forms():
         m_got, c = ptgpu.camera_apply_input(c, pressed, held, mouse, ft)
         assert m_got == m_ref
         assert list(c.origin) == list(o_ref) and list(c.look_at) == list(la_ref), step
+
+
+@pytest.mark.parametrize("name,param", [("random_scene", 0), ("final_book_two", 0), ("cornell_smoke", 0),
+                                        ("cornell_box", 0), ("sphere_cloud", 20000)])
+def test_accel_tree_invariants(name, param):
+    """The fast-mode SAH tree: every primitive op of the flattened scene in exactly one leaf, every child box
+    encloses its subtree (transformed and moving primitives included), depth below the traversal stack cap."""
+    scene = ptgpu.Scene.named(name, 1.5, param=param)
+    info = scene.accel_info()
+    flat = scene.flatten_info()
+    assert 0 < info["n_prims"] <= flat["n_leaves"]  # medium boundaries own a leaf record but are not traversal ops
+    assert 1 <= info["n_nodes"] < info["n_prims"]
+    assert info["depth"] < 32
