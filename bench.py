@@ -41,7 +41,7 @@ def algorithmic_bytes(V, P):
     return b_ray, b_shade, b_fused
 
 
-def cpu_baseline(scene, width, height, max_depth, target_seconds=12.0):
+def cpu_baseline(scene, width, height, max_depth, target_seconds=12.0, name="cornell_box"):
     """Times the CPU oracle (f64 restatement of the reference, tile jobs on a thread pool) on a bounded sample
     of the same workload: the same scene and image size at a reduced spp."""
     import oracle_binding as ob
@@ -58,7 +58,7 @@ def cpu_baseline(scene, width, height, max_depth, target_seconds=12.0):
         "unit": "Mpaths/s",
         "cores": int(st.threads),
         "kind": "port",
-        "sample": f"cornell_box {width}x{height} @ {spp} spp, max_depth {max_depth}, {st.seconds:.1f} s "
+        "sample": f"{name} {width}x{height} @ {spp} spp, max_depth {max_depth}, {st.seconds:.1f} s "
                   f"(f64 recursive oracle, {st.tiles} tile jobs)",
         "S": st.segments / st.paths,
         "V": st.node_visits / st.segments,
@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--scene", default="cornell_box")
+    ap.add_argument("--scene-param", type=int, default=0, help="recipe parameter (sphere_cloud: sphere count)")
     ap.add_argument("--paths-in-flight", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode side measurement")
@@ -100,7 +101,7 @@ def main():
     tiles = importlib.import_module("path-tracer_amd.tiles")
     STRIPE_ROWS = tiles.STRIPE_ROWS
     W, H = args.width, args.height
-    scene = pt.Scene.named(args.scene, W / H, seed=SEED)
+    scene = pt.Scene.named(args.scene, W / H, seed=SEED, param=args.scene_param)
     ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight,
                      flags=pt.PT_CFG_PROFILE_STAGES)
     ctx.upload(scene)
@@ -162,7 +163,7 @@ def main():
         cpu = None
         V, P = 6.8, 8.8  # Cornell box counters from the oracle; replaced by the live ones below
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(scene, W, H, args.max_depth)
+            cpu = cpu_baseline(scene, W, H, args.max_depth, name=args.scene)
             V, P = cpu["V"], cpu["P"]
         b_ray, b_shade, b_fused = algorithmic_bytes(V, P)
         n_launch = max(int(st.profiled_bounce_launches), 1)
@@ -187,7 +188,8 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "Mpaths/sec (pixels x spp / s), Cornell box offline render",
+            "metric": "Mpaths/sec (pixels x spp / s), Cornell box offline render" if args.scene == "cornell_box"
+            else f"Mpaths/sec (pixels x spp / s), {args.scene} offline render",
             "value": value,
             "unit": "Mpaths/s",
             "n_gpus": world,

@@ -660,7 +660,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_extend_accel(Queue q, SceneView s
         };
         int32_t node = 0;
         int sp = 0;
-        for (;;) {
+        // A ray with a NaN component passes EVERY slab test (min / max drop NaNs; the reference's comparisons all
+        // come out false, src/math/aabb.rs:27-47), i.e. it would walk the whole tree, a million nodes, to find at
+        // best a NaN hit distance. Such rays exist by the reference's own semantics (a light sample taken from
+        // inside the sphere light shape, src/sphere.rs:92-100) and their paths are NaN whatever they hit, so fast
+        // mode does not trace them: they miss.
+        const double probe = (o.x + o.y + o.z) + (d.x + d.y + d.z);
+        const bool traceable = probe == probe && fabs(probe) <= kF64Max;
+        while (traceable) {
             const AccelNode &n = nodes[node];
             double t0, t1;
             bool h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
