@@ -120,6 +120,16 @@ struct BuildPrim {
     int32_t op; // index into flat.ops
 };
 
+// f32 values that bracket an f64 value
+float round_down(double v) {
+    float f = (float)v;
+    return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+}
+float round_up(double v) {
+    float f = (float)v;
+    return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
+
 struct Builder {
     std::vector<BuildPrim> prims;
     std::vector<AccelNode> nodes;
@@ -128,7 +138,7 @@ struct Builder {
     bool too_deep = false;
 
     static constexpr int kBins = 16;
-    static constexpr int kLeafMax = 4;
+    static constexpr int kLeafMax = 4; // a leaf reference holds its count in 3 bits
 
     // Returns the child reference for prims[first, first + n): an inner node index or ~first_leaf_prim, plus count.
     void build_child(int first, int n, int depth, int32_t &child, int32_t &count, Box &box) {
@@ -152,7 +162,7 @@ struct Builder {
             too_deep = true;
         }
         if (split < 0) {
-            child = ~(int32_t)order.size();
+            child = accel_leaf_ref((int32_t)order.size(), n);
             count = n;
             for (int i = first; i < first + n; ++i) order.push_back(prims[i].op);
             return;
@@ -167,11 +177,10 @@ struct Builder {
         AccelNode &nd = nodes[me];
         for (int s = 0; s < 2; ++s) {
             for (int a = 0; a < 3; ++a) {
-                nd.lo[s][a] = b[s].lo[a];
-                nd.hi[s][a] = b[s].hi[a];
+                nd.lo[s][a] = round_down(b[s].lo[a]);
+                nd.hi[s][a] = round_up(b[s].hi[a]);
             }
             nd.child[s] = c[s];
-            nd.count[s] = k[s];
         }
         child = me;
         count = 0;
@@ -373,8 +382,9 @@ extern "C" int pt_scene_accel_info(const pt_scene_desc *scene, int32_t *n_nodes,
         for (int s = 0; s < 2; ++s) {
             Box b;
             if (n.child[s] >= 0) b = sub[n.child[s]];
-            else if (!leaf_box(~n.child[s], n.count[s], b)) return PT_ERR_INVALID_ARG;
-            if (!inside(b, n.lo[s], n.hi[s])) return PT_ERR_INVALID_ARG;
+            else if (!leaf_box((~n.child[s]) >> 3, (~n.child[s]) & 7, b)) return PT_ERR_INVALID_ARG;
+            const double lo[3] = {n.lo[s][0], n.lo[s][1], n.lo[s][2]}, hi[3] = {n.hi[s][0], n.hi[s][1], n.hi[s][2]};
+            if (!inside(b, lo, hi)) return PT_ERR_INVALID_ARG;
             sub[id].grow(b);
         }
     }

@@ -12,14 +12,18 @@
 
 namespace ptdev {
 
-struct AccelNode { // 128 bytes = one L2 line: the boxes of BOTH children, so that one fetch decides both
-    double lo[2][3];
-    double hi[2][3];
-    int32_t child[2]; // >= 0: inner node index; < 0: leaf, first primitive = ~child
-    int32_t count[2]; // primitives of a leaf child (0 for an inner child)
-    int32_t pad[4];
+// 64 bytes: the boxes of BOTH children, so that one fetch decides both. The tree of a million primitives does not
+// fit the 4 MiB L2 of an XCD, so traversal speed is bytes per node visit. Boxes are stored in f32, rounded OUTWARD
+// (never smaller than the f64 box), and the slab test runs in f64 on the widened values with the f64 ray: no
+// rounding analysis is needed for it to be conservative, and the primitive tests stay f64.
+struct AccelNode {
+    float lo[2][3];
+    float hi[2][3];
+    int32_t child[2]; // >= 0: inner node index; < 0: leaf, ~child = (first primitive << 3) | count, count <= 7
+    int32_t pad[2];
 };
-static_assert(sizeof(AccelNode) == 128, "AccelNode must be 128 bytes");
+static_assert(sizeof(AccelNode) == 64, "AccelNode must be 64 bytes");
+inline int32_t accel_leaf_ref(int32_t first, int32_t count) { return ~((first << 3) | count); }
 
 constexpr int kAccelMaxDepth = 32; // traversal stack entries per ray (32 KiB of LDS per 256-thread workgroup)
 

@@ -611,13 +611,13 @@ __global__ __launch_bounds__(kBlock) void k_extend_list(Queue q, SceneView sv, E
 
 // ------------------------------------------------------------------------------------------------------------
 // Fast-mode traversal of the SAH tree built at upload (accel.h): per-lane, nearer child first, the far child on a
-// per-lane stack in LDS. A node record holds the boxes of both children, so one 128-B fetch decides both.
+// per-lane stack in LDS. A node record holds the boxes of both children, so one 64-B fetch decides both.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool accel_box(const double *lo, const double *hi, D3 o, D3 inv, double t_min, double t_max,
+__device__ __forceinline__ bool accel_box(const float *lo, const float *hi, D3 o, D3 inv, double t_min, double t_max,
                                           double &t_near) {
-    const double x0 = (lo[0] - o.x) * inv.x, x1 = (hi[0] - o.x) * inv.x;
-    const double y0 = (lo[1] - o.y) * inv.y, y1 = (hi[1] - o.y) * inv.y;
-    const double z0 = (lo[2] - o.z) * inv.z, z1 = (hi[2] - o.z) * inv.z;
+    const double x0 = ((double)lo[0] - o.x) * inv.x, x1 = ((double)hi[0] - o.x) * inv.x;
+    const double y0 = ((double)lo[1] - o.y) * inv.y, y1 = ((double)hi[1] - o.y) * inv.y;
+    const double z0 = ((double)lo[2] - o.z) * inv.z, z1 = ((double)hi[2] - o.z) * inv.z;
     const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), t_min));
     const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), t_max));
     t_near = tn;
@@ -673,18 +673,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_extend_accel(Queue q, SceneView s
             bool h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
             bool h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
             const int32_t c0 = n.child[0], c1 = n.child[1];
-            const int32_t k0 = n.count[0], k1 = n.count[1];
             // leaf children are tested on the spot, nearer one first so that the farther may be skipped
             if (h0 && h1 && c0 < 0 && c1 < 0 && t1 < t0) {
-                leaf(~c1, k1);
+                leaf((~c1) >> 3, (~c1) & 7);
                 h1 = false;
             }
             if (h0 && c0 < 0) {
-                if (t0 <= closest) leaf(~c0, k0);
+                if (t0 <= closest) leaf((~c0) >> 3, (~c0) & 7);
                 h0 = false;
             }
             if (h1 && c1 < 0) {
-                if (t1 <= closest) leaf(~c1, k1);
+                if (t1 <= closest) leaf((~c1) >> 3, (~c1) & 7);
                 h1 = false;
             }
             h0 = h0 && t0 <= closest;
