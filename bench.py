@@ -3,9 +3,9 @@
 1024 x 1024 @ 1024 spp, max_depth 50 (the offline configuration of the reference: src/lib.rs:128-135),
 on N GPUs of one node.
 
-A step is one full render of the image. With N > 1 the image is cut into 64-row stripes dealt round-robin to the
-ranks (one process per GPU); every rank renders its stripes into its own copy of the f32 RGBA image and the
-stripes are gathered to rank 0 with one RCCL gather (torch.distributed, backend "nccl") inside the timed region.
+A step is one full render of the image. With N > 1 the scanlines are dealt to the ranks (one process per GPU) by
+interleaving: rank r traces rows r, r + N, ... into its own copy of the f32 RGBA image in one pt_render call, and the
+rows are gathered to rank 0 with one RCCL gather (torch.distributed, backend "nccl") inside the timed region.
 The scene and the RNG are keyed by global pixel and sample index, so the image does not depend on N.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
@@ -99,7 +99,6 @@ def main():
 
     pt = importlib.import_module("path-tracer_amd")
     tiles = importlib.import_module("path-tracer_amd.tiles")
-    STRIPE_ROWS = tiles.STRIPE_ROWS
     W, H = args.width, args.height
     scene = pt.Scene.named(args.scene, W / H, seed=SEED, param=args.scene_param)
     ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight,
@@ -109,10 +108,9 @@ def main():
     # The image lives in a torch tensor so that RCCL can move it; the library renders straight into it.
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     ctx.bind_image(image.data_ptr(), W, H)
-    my_stripes = tiles.stripes_for(rank, world, H)
     pack = gather_list = None
     if world > 1:
-        pack = torch.zeros((tiles.max_stripes(world, H), STRIPE_ROWS, W, 4), dtype=torch.float32, device=image.device)
+        pack = torch.zeros((tiles.max_rows(world, H), W, 4), dtype=torch.float32, device=image.device)
         if rank == 0:
             gather_list = [torch.zeros_like(pack) for _ in range(world)]
 
@@ -120,9 +118,8 @@ def main():
         if world == 1:
             ctx.render(W, H, args.spp, args.max_depth, frame=frame)
             return
-        for (y0, y1) in my_stripes:
-            ctx.render(W, H, args.spp, args.max_depth, tile=(0, y0, W, y1), frame=frame)
-        tiles.gather_stripes(image, rank, world, dist, pack=pack, gather_list=gather_list)
+        ctx.render(W, H, args.spp, args.max_depth, frame=frame, rows=tiles.rows_for(rank, world))
+        tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
 
     def barrier():
         if dist is not None:
@@ -203,7 +200,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene} {W}x{H} @ {args.spp} spp, max_depth {args.max_depth}, "
-                            f"{'one tile' if world == 1 else f'{STRIPE_ROWS}-row stripes round-robin + RCCL gather'}",
+                            f"{'one tile' if world == 1 else f'rows interleaved over {world} GPUs + RCCL gather'}",
                 "paths_in_flight": args.paths_in_flight,
                 "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
                 "nan_pixel_fraction": nan_frac,

@@ -200,6 +200,9 @@ typedef struct pt_render_args {
     uint32_t mode;            /* pt_render_mode */
     uint32_t frame;           /* dispatch number; salts the RNG so successive realtime frames differ */
     uint32_t flags;           /* pt_render_flags */
+    uint32_t row_step;        /* 0 or 1: every row of [y0, y1). k > 1: only rows y0 + row_phase + m k < y1, the split */
+    uint32_t row_phase;       /* of a tile between k GPUs by interleaved rows (no reference counterpart: the        */
+                              /* reference's tiles are rectangles, src/lib.rs:380-394); row_phase < row_step          */
 } pt_render_args;
 
 /* PT_RENDER_BOOK_SEMANTICS: Isotropic scatters as in the book instead of as in the reference. The reference's

@@ -874,6 +874,8 @@ void trace_tile(const RenderJob &job, uint32_t x0, uint32_t y0, uint32_t x1, uin
     const bool realtime = a.mode == PT_MODE_REALTIME;
     for (uint32_t jj = y1; jj-- > y0;) { /* rows top to bottom of the tile, trace.rs:135 */
         uint32_t j = jj;
+        /* interleaved split of a tile between GPUs (no reference counterpart): only rows y0 + phase + m * step */
+        if (a.row_step > 1 && (j < a.y0 + a.row_phase || (j - a.y0 - a.row_phase) % a.row_step != 0)) continue;
         float *row = job.rgba + ((size_t)j * a.width) * 4;
         for (uint32_t i = x0; i < x1; ++i) {
             uint64_t pixel = (uint64_t)j * a.width + i;

@@ -177,6 +177,8 @@ class RenderArgs(C.Structure):
         ("mode", C.c_uint32),
         ("frame", C.c_uint32),
         ("flags", C.c_uint32),
+        ("row_step", C.c_uint32),
+        ("row_phase", C.c_uint32),
     ]
 
 
@@ -460,9 +462,11 @@ class Context:
     def set_camera(self, cam: Camera):
         self._check(lib.pt_camera_set(self._h, C.byref(cam)), "pt_camera_set")
 
-    def render(self, width, height, spp, max_depth, tile=None, mode=PT_MODE_OFFLINE, frame=0, flags=0):
+    def render(self, width, height, spp, max_depth, tile=None, mode=PT_MODE_OFFLINE, frame=0, flags=0, rows=None):
+        """rows = (step, phase): trace only rows y0 + phase + m * step of the tile (interleaved split between GPUs)."""
         x0, y0, x1, y1 = tile if tile is not None else (0, 0, width, height)
-        a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags)
+        step, phase = rows if rows is not None else (1, 0)
+        a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags, step, phase)
         self._check(lib.pt_render(self._h, C.byref(a)), "pt_render")
         self.width, self.height = width, height
 

@@ -90,6 +90,7 @@ struct PassParams {
     uint32_t frame;
     uint32_t width, height; // image size
     uint32_t cx0, cy0;      // first pixel of the chunk
+    uint32_t row_step;      // image rows between consecutive chunk rows (1 unless rows are interleaved between GPUs)
     uint32_t cw;            // chunk width in pixels (== tile width)
     uint32_t cpix;          // pixels in the chunk
     uint32_t s_base;        // first sample index of this pass
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Queue q, QueueShape sh, doubl
             const uint32_t p = pid % pp.cpix;
             s = pid / pp.cpix;
             i = pp.cx0 + p % pp.cw;
-            jy = pp.cy0 + p / pp.cw;
+            jy = pp.cy0 + (p / pp.cw) * pp.row_step;
             pixel = (uint64_t)jy * pp.width + i;
             if (REALTIME) alive = !(pixel_skip_draw(pp.seed, pp.frame, pixel) < 0.8); // src/trace.rs:144
         }
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const doub
             continue;
         }
         const uint32_t i = pp.cx0 + p % pp.cw;
-        const uint32_t j = pp.cy0 + p / pp.cw;
+        const uint32_t j = pp.cy0 + (p / pp.cw) * pp.row_step;
         const uint64_t pixel = (uint64_t)j * pp.width + i;
         float *px = image + pixel * 4;
         const double ns = (double)pp.spp;
@@ -1774,7 +1775,12 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
     if (rc != PT_OK) return rc;
     ctx->render_flags = a->flags;
 
-    const uint32_t tw = a->x1 - a->x0, th = a->y1 - a->y0;
+    const uint32_t row_step = a->row_step ? a->row_step : 1u;
+    if (a->row_phase >= row_step) return set_error(ctx, PT_ERR_INVALID_ARG, "row_phase must be below row_step");
+    const uint32_t span = a->y1 - a->y0;
+    if (a->row_phase >= span) return PT_OK; // none of this tile's rows belong to the phase
+    // rows y0 + phase + m * step below y1
+    const uint32_t tw = a->x1 - a->x0, th = (span - a->row_phase + row_step - 1) / row_step;
     if (tw > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "tile row wider than the paths-in-flight budget");
     // chunk = as many whole tile rows as fit the budget with at least one sample each
     const uint32_t rows_per_chunk = std::max<uint32_t>(1, std::min<uint32_t>(th, ctx->capacity / tw));
@@ -1790,7 +1796,8 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
         pp.width = a->width;
         pp.height = a->height;
         pp.cx0 = a->x0;
-        pp.cy0 = a->y0 + r0;
+        pp.cy0 = a->y0 + a->row_phase + r0 * row_step;
+        pp.row_step = row_step;
         pp.cw = tw;
         pp.cpix = rows * tw;
         pp.spp = a->spp;

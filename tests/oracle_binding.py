@@ -95,9 +95,10 @@ def intersect(desc, rays, t_min=0.001, t_max=F64_MAX, medium_seed=0):
     return hits, st
 
 
-def render(desc, camera, width, height, spp, max_depth, seed=0x5EED0001, tile=None, mode=0, frame=0, threads=0, image=None, counts=None, flags=0):
+def render(desc, camera, width, height, spp, max_depth, seed=0x5EED0001, tile=None, mode=0, frame=0, threads=0, image=None, counts=None, flags=0, rows=None):
     x0, y0, x1, y1 = tile if tile is not None else (0, 0, width, height)
-    a = ptgpu.RenderArgs(C.sizeof(ptgpu.RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags)
+    step, phase = rows if rows is not None else (1, 0)
+    a = ptgpu.RenderArgs(C.sizeof(ptgpu.RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags, step, phase)
     if image is None:
         image = np.zeros((height, width, 4), dtype=np.float32)
     st = OracleStats()

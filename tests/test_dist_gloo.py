@@ -25,6 +25,32 @@ def _free_port():
     return port
 
 
+def _worker_rows(rank, world, port, out_path):
+    """The split bench.py uses: rows interleaved between ranks, one render call and one gather per rank."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pt = importlib.import_module("path-tracer_amd")
+    tiles = importlib.import_module("path-tracer_amd.tiles")
+    import oracle_binding as ob
+
+    scene = pt.Scene.named("cornell_box", W / H)
+    image = np.zeros((H, W, 4), dtype=np.float32)
+    ob.render(scene.desc(), scene.camera, W, H, SPP, DEPTH, threads=1, image=image, rows=tiles.rows_for(rank, world))
+    # only this rank's rows were written
+    others = np.ones(H, dtype=bool)
+    others[rank::world] = False
+    assert not image[others].any()
+    t = torch.from_numpy(image)
+    tiles.gather_rows(t, rank, world, dist)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,3 +86,17 @@ def test_stripe_gather_matches_single_process(tmp_path, world):
     ref, _ = ob.render(scene.desc(), scene.camera, W, H, SPP, DEPTH, threads=1)
     assert np.array_equal(got, ref, equal_nan=True)
     assert np.nanmax(ref) > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_interleaved_rows_gather_matches_single_process(tmp_path, world):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import ptgpu
+
+    out = str(tmp_path / "gathered_rows.npy")
+    mp.spawn(_worker_rows, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    scene = ptgpu.Scene.named("cornell_box", W / H)
+    ref, _ = ob.render(scene.desc(), scene.camera, W, H, SPP, DEPTH, threads=1)
+    assert np.array_equal(got, ref, equal_nan=True)

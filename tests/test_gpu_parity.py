@@ -308,3 +308,26 @@ def test_book_semantics_smoke_scene(any_ctx):
     assert rmse <= (1e-6 if exact else 0.05)
     ctx.render(w, h, 8, 12)
     assert np.isnan(ctx.readback()[..., :3]).any()  # reference semantics: 0 * x / 0 on medium scatters
+
+
+def test_interleaved_rows_assemble_the_full_image(gpu_ctx):
+    """pt_render_args.row_step / row_phase: the three interleaved thirds of an image, and of a tile of it, are
+    bit-identical to the rows of the whole render (RNG keyed by global pixel and sample)."""
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    gpu_ctx.upload(scene)
+    W, H = 80, 50
+    gpu_ctx.reset()
+    gpu_ctx.render(W, H, 4, 10)
+    whole = gpu_ctx.readback()
+    for tile in (None, (8, 5, 72, 44)):
+        x0, y0, x1, y1 = tile if tile else (0, 0, W, H)
+        for phase in range(3):
+            gpu_ctx.reset()
+            gpu_ctx.render(W, H, 4, 10, tile=tile, rows=(3, phase))
+            part = gpu_ctx.readback()
+            mask = np.zeros((H, W), dtype=bool)
+            mask[y0 + phase:y1:3, x0:x1] = True
+            assert np.array_equal(part[mask], whole[mask], equal_nan=True)
+            assert not part[~mask].any()
+    with pytest.raises(ptgpu.PtError):
+        gpu_ctx.render(W, H, 1, 4, rows=(2, 2))
