@@ -80,7 +80,13 @@ def main():
     ap.add_argument("--paths-in-flight", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode side measurement")
+    ap.add_argument("--realtime", action="store_true",
+                    help="progressive frames instead of the offline render (src/lib.rs:118-123: spp 1, depth 10, "
+                         "80 %% pixel skip, running mean); pass --width 1920 --height 1080 --steps <frames>")
     args = ap.parse_args()
+    if args.realtime:
+        args.spp, args.max_depth = 1, 10
+        args.no_cpu_baseline = args.no_exact = True
 
     import torch
 
@@ -115,10 +121,11 @@ def main():
             gather_list = [torch.zeros_like(pack) for _ in range(world)]
 
     def step(frame):
+        mode = pt.PT_MODE_REALTIME if args.realtime else pt.PT_MODE_OFFLINE
         if world == 1:
-            ctx.render(W, H, args.spp, args.max_depth, frame=frame)
+            ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode)
             return
-        ctx.render(W, H, args.spp, args.max_depth, frame=frame, rows=tiles.rows_for(rank, world))
+        ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, rows=tiles.rows_for(rank, world))
         tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
 
     def barrier():
@@ -152,7 +159,8 @@ def main():
         ctx_x.render(W, H, spp_x, args.max_depth, frame=1)
         exact_value = float(W) * H * spp_x / (time.perf_counter() - t_x) / 1e6
         ctx_x.close()
-    paths_total = float(W) * H * args.spp * args.steps
+    # a realtime frame traces the pixels that pass the 80 % skip (src/trace.rs:144): 20 % of them on average
+    paths_total = float(W) * H * args.spp * args.steps * (0.2 if args.realtime else 1.0)
     value = paths_total / elapsed / 1e6
     result = None
     if rank == 0:
@@ -185,7 +193,8 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "Mpaths/sec (pixels x spp / s), Cornell box offline render" if args.scene == "cornell_box"
+            "metric": f"Mpaths/sec (traced pixels x spp / s), {args.scene} realtime frames" if args.realtime
+            else "Mpaths/sec (pixels x spp / s), Cornell box offline render" if args.scene == "cornell_box"
             else f"Mpaths/sec (pixels x spp / s), {args.scene} offline render",
             "value": value,
             "unit": "Mpaths/s",
@@ -200,8 +209,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene} {W}x{H} @ {args.spp} spp, max_depth {args.max_depth}, "
+                            f"{'realtime progressive frames (80 % pixel skip), ' if args.realtime else ''}"
                             f"{'one tile' if world == 1 else f'rows interleaved over {world} GPUs + RCCL gather'}",
                 "paths_in_flight": args.paths_in_flight,
+                "frames_per_s": (args.steps / elapsed) if args.realtime else None,
                 "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
                 "nan_pixel_fraction": nan_frac,
                 "arithmetic": "f64 rays, intersections and throughput; f32 direction sampling and pdf weights; "
