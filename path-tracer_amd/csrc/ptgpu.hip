@@ -496,7 +496,12 @@ __device__ __forceinline__ bool box_pred(const double *pb, D3 o, D3 inv, double 
     // entering through the max plane means travelling in -axis; leaving through it, in +axis
     const bool max_plane = entry ? (ia < 0.0) : (ia > 0.0);
     face = (2 - axis) * 2 + (max_plane ? 0 : 1);
-    return (tn <= tf) & !(t < t_min) & !(t > t_max);
+    // A rectangle accepts t == t_max (src/rect.rs:99), but a box is reached through the BVH node that holds it,
+    // whose bounds are exactly the box, and AABB::hit rejects an interval that has shrunk to a point
+    // (`tmax <= tmin`, src/math/aabb.rs:41): a box ENTERED exactly at the current closest distance is never
+    // tested. That is what decides coplanar pairs such as a box standing on a floor seen from below.
+    const bool in_range = entry ? (t < t_max) : !(t > t_max);
+    return (tn <= tf) & !(t < t_min) & in_range;
 }
 
 // Closest hit over the fused kernels' op list (see pt_scene_upload): no BOX ops, and a primitive's transform chain

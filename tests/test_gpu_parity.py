@@ -331,3 +331,93 @@ def test_interleaved_rows_assemble_the_full_image(gpu_ctx):
             assert not part[~mask].any()
     with pytest.raises(ptgpu.PtError):
         gpu_ctx.render(W, H, 1, 4, rows=(2, 2))
+
+
+def _kitchen_sink_scene(lift=0.5):
+    """A short-list scene (fast mode walks it without boxes, boxes by slabs) with every primitive form: rectangles on
+    the three axes, one flipped, a sphere, a plain box, and boxes under translate / rotate-y wrappers."""
+    s = ptgpu.Scene()
+    white = s.lambertian(s.texture_constant((0.7, 0.7, 0.7)))
+    red = s.lambertian(s.texture_constant((0.7, 0.1, 0.1)))
+    glass = s.dielectric(1.5)
+    light = s.diffuse_light(s.texture_constant((9, 9, 9)))
+    nodes = [
+        s.rect(0, 100, 0, 100, 0, 0, white),                     # x = 0
+        s.flip_normals(s.rect(0, 100, 0, 100, 100, 0, red)),     # x = 100, flipped
+        s.rect(0, 100, 0, 100, 0, 1, white),                     # y = 0
+        s.flip_normals(s.rect(30, 70, 30, 70, 99, 1, light)),    # light below the ceiling
+        s.rect(0, 100, 0, 100, 100, 2, white),                   # z = 100
+        s.sphere((70, 20, 30), 15.0, glass),
+        s.box((10, lift, 10), (30, 25, 30), white),
+        s.translate(s.rotate_y(s.box((0, 0, 0), (20, 50, 20), red), 25.0), (40, lift, 55)),
+        s.translate(s.box((0, 0, 0), (12, 12, 12), white), (75, 40, 70)),
+        s.rotate_y(s.box((-8, 60, -8), (8, 76, 8), white), -40.0),
+    ]
+    s.set_root(s.bvh(nodes))
+    s.set_lights([s.rect(30, 70, 30, 70, 99, 1, white)])
+    s.camera = ptgpu.make_camera((50, 50, -120), (50, 50, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return s
+
+
+def _random_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=ptgpu.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-20, 120, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.2, 5.0, size=(n, 1))
+    rays["time"] = rng.uniform(0, 1, size=n)
+    rays["direction"][: n // 10, 1] = 0.0  # a tenth of the rays run exactly parallel to the floor
+    return rays
+
+
+def test_list_walk_random_rays(any_ctx):
+    """Random rays from everywhere (inside the boxes and the sphere included) through the fused kernels' list walk:
+    straight-line rectangle / sphere tests and the slab form of the six-rectangle box must report the same primitive,
+    face (via the normal), and distance as the oracle's rectangle-by-rectangle recursion."""
+    gpu_ctx, exact = any_ctx
+    scene = _kitchen_sink_scene()
+    assert scene.flatten_info()["n_leaves"] <= 24
+    gpu_ctx.upload(scene)
+    rays = _random_rays(200_000, 123)
+    ref, _ = ob.intersect(scene.desc(), rays)
+    got = gpu_ctx.intersect(rays)
+    frac, max_rel, both = _compare_hits(got, ref)
+    assert both.mean() > 0.3
+    assert frac >= 0.9999, f"primitive ids agree on {frac:.6f} of rays"
+    assert max_rel <= (1e-12 if exact else 1e-7), f"max relative t error {max_rel:.3e}"
+    assert np.allclose(got["normal"][both], ref["normal"][both], rtol=1e-9, atol=1e-9)
+    assert np.allclose(got["p"][both], ref["p"][both], rtol=1e-6, atol=1e-6)
+    # and the render of the same scene agrees with the oracle's
+    w = h = 40
+    gpu_ctx.render(w, h, 4, 12)
+    img = gpu_ctx.readback()[..., :3].astype(np.float64)
+    oref, _ = ob.render(scene.desc(), scene.camera, w, h, 4, 12, seed=gpu_ctx.seed, threads=4)
+    oref = oref[..., :3].astype(np.float64)
+    finite = np.isfinite(img) & np.isfinite(oref)
+    rmse = np.sqrt(np.mean((img[finite] - oref[finite]) ** 2)) / max(np.sqrt(np.mean(oref[finite] ** 2)), 1e-12)
+    assert rmse <= (1e-6 if exact else 0.05)
+
+
+def test_coplanar_faces_tie_rule(any_ctx):
+    """Boxes standing exactly on the floor, seen from below: the floor and a box's bottom face lie at the same
+    distance. The reference settles the pair through `AABB::hit` of the box's BVH node, which compares a product with
+    the reciprocal (`(min - o) * (1 / d)`, src/math/aabb.rs:31-33) against the earlier hit's quotient
+    (`(k - o) / d`, src/rect.rs:63-69); whether the box survives that cull depends on how those two round. Exact mode
+    repeats both roundings and agrees on every ray; fast mode has one rounding for both and settles every such pair
+    for the first hit, which differs from the reference on a few rays in ten thousand of this adversarial batch."""
+    gpu_ctx, exact = any_ctx
+    scene = _kitchen_sink_scene(lift=0.0)
+    gpu_ctx.upload(scene)
+    rays = _random_rays(200_000, 123)
+    ref, _ = ob.intersect(scene.desc(), rays)
+    got = gpu_ctx.intersect(rays)
+    frac, max_rel, both = _compare_hits(got, ref)
+    assert max_rel <= (1e-12 if exact else 1e-7)
+    if exact:
+        assert frac == 1.0
+    else:
+        assert frac >= 0.999
+        bad = got["prim"] != ref["prim"]
+        # every disagreement is such a pair: same distance to rounding, both on the plane y = 0
+        assert np.allclose(got["t"][bad], ref["t"][bad], rtol=1e-12)
+        assert np.allclose(got["p"][bad][:, 1], 0.0, atol=1e-9)
