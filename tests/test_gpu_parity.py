@@ -421,3 +421,37 @@ def test_coplanar_faces_tie_rule(any_ctx):
         # every disagreement is such a pair: same distance to rounding, both on the plane y = 0
         assert np.allclose(got["t"][bad], ref["t"][bad], rtol=1e-12)
         assert np.allclose(got["p"][bad][:, 1], 0.0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,lo,hi", [("final_book_two", -200.0, 700.0), ("random_scene", -12.0, 12.0),
+                                        ("cornell_smoke", -50.0, 600.0)])
+def test_random_rays_through_the_tree(any_ctx, name, lo, hi):
+    """Rays from anywhere in the scene volume (inside spheres, boxes and media included, every shutter time): fast
+    mode finds them through its SAH tree, exact mode through the reference's tree; both must report the oracle's
+    primitive and distance."""
+    gpu_ctx, exact = any_ctx
+    scene = ptgpu.Scene.named(name, 1.0)
+    gpu_ctx.upload(scene)
+    rng = np.random.default_rng(99)
+    n = 100_000
+    rays = np.zeros(n, dtype=ptgpu.RAY_DTYPE)
+    rays["origin"] = rng.uniform(lo, hi, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, size=(n, 1))
+    rays["time"] = rng.uniform(0, 1, size=n)
+    ref, _ = ob.intersect(scene.desc(), rays, medium_seed=3)
+    got = gpu_ctx.intersect(rays, medium_seed=3)
+    frac, max_rel, both = _compare_hits(got, ref)
+    assert both.mean() > 0.2
+    assert max_rel <= (1e-12 if exact else 1e-7), f"{name}: max relative t error {max_rel:.3e}"
+    if exact:
+        assert frac >= 0.9999, f"{name}: primitive ids agree on {frac:.6f} of rays"
+        return
+    # Rays that START inside the touching ground boxes of the final scene leave through a face that two boxes share:
+    # two rectangles of different boxes at exactly the same distance, which the reference settles by the order of
+    # its tree and fast mode by the order of another. Anything else must be the same primitive.
+    bad = got["prim"] != ref["prim"]
+    assert np.allclose(got["t"][bad], ref["t"][bad], rtol=1e-9), "a disagreement that is not an exact tie"
+    assert np.allclose(np.abs(got["normal"][bad]), np.abs(ref["normal"][bad]), atol=1e-9)
+    assert (got["material"][bad] == ref["material"][bad]).all()
+    assert frac >= (0.98 if name == "final_book_two" else 0.9999), f"{name}: primitive ids agree on {frac:.6f} of rays"
