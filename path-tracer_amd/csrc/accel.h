@@ -25,7 +25,7 @@ struct AccelNode {
 static_assert(sizeof(AccelNode) == 64, "AccelNode must be 64 bytes");
 inline int32_t accel_leaf_ref(int32_t first, int32_t count) { return ~((first << 3) | count); }
 
-constexpr int kAccelMaxDepth = 32; // traversal stack entries per ray (32 KiB of LDS per 256-thread workgroup)
+constexpr int kAccelMaxDepth = 28; // traversal stack entries per ray (32 KiB of LDS per 256-thread workgroup)
 
 struct Accel {
     std::vector<AccelNode> nodes; // nodes[0] is the root

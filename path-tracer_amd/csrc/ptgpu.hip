@@ -631,7 +631,7 @@ __device__ __forceinline__ bool accel_box(const float *lo, const float *hi, D3 o
 }
 
 template <bool MEDIA>
-__global__ __launch_bounds__(kBlock, 4) void k_extend_accel(Queue q, SceneView sv, const AccelNode *nodes,
+__global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q, SceneView sv, const AccelNode *nodes,
                                                          const DevOp *prims, ExtendArgs a) {
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
     const uint32_t n_virtual = ((max_shard_count(a.counts, a.sh.shards) + kBlock - 1) / kBlock) << a.sh.shift;
