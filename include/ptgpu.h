@@ -316,6 +316,13 @@ int pt_scene_bounding_box(const pt_scene *s, int node, double t0, double t1, dou
 int pt_scene_flatten_info(const pt_scene_desc *scene, int32_t *n_ops, int32_t *n_leaves, int32_t *n_xforms,
                           int32_t *max_frame_depth);
 
+/* Replaces rebuilding the tree for a new shutter window, BvhNode::from_list(list, time0, time1) (src/bvh.rs:13,60-61;
+ * the main loop advances the window every frame, src/lib.rs:412-417): moving spheres' bounds are recomputed for
+ * [time0, time1] and the fast-mode tree is refitted on the device, bottom up, one launch per level. A scene walked as
+ * a primitive list has no boxes and needs nothing (PT_OK). Exact mode walks the reference's host-built tree, whose
+ * boxes are part of the uploaded scene: PT_ERR_UNSUPPORTED_SCENE (rebuild with pt_scene_bvh and upload). */
+int pt_scene_refit(pt_ctx *ctx, double time0, double time1);
+
 /* Fast mode traces scenes that are not a short primitive list through a SAH tree over the same primitives, built on
  * the host at upload (no reference counterpart: it stands in for walking BvhNode::from_list's tree, src/bvh.rs:13-99,
  * and returns the same closest hit up to exact ties). This builds that tree for a scene and checks it on the host:

@@ -223,7 +223,7 @@ EXPORTS = [
     "pt_scene_flip_normals", "pt_scene_translate", "pt_scene_rotate_y", "pt_scene_constant_medium", "pt_scene_list",
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
     "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
-    "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_abi_version",
+    "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_abi_version",
 ]
 
 _vp = C.c_void_p
@@ -287,6 +287,7 @@ _sig("pt_session_new", C.c_int, _vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, 
 _sig("pt_session_free", None, _vp)
 _sig("pt_session_frame", C.c_int, _vp, C.POINTER(UserInput), C.c_double, C.POINTER(FrameInfo))
 _sig("pt_scene_accel_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p)
+_sig("pt_scene_refit", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_abi_version", C.c_uint32)
 
 
@@ -469,6 +470,10 @@ class Context:
         a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags, step, phase)
         self._check(lib.pt_render(self._h, C.byref(a)), "pt_render")
         self.width, self.height = width, height
+
+    def refit(self, time0, time1):
+        """Refits the fast-mode tree for the shutter window [time0, time1] (pt_scene_refit)."""
+        self._check(lib.pt_scene_refit(self._h, float(time0), float(time1)), "pt_scene_refit")
 
     def reset(self):
         self._check(lib.pt_accum_reset(self._h), "pt_accum_reset")

@@ -306,6 +306,31 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
     }
     out.nodes.swap(bld.nodes);
     out.depth = bld.max_depth;
+    { // parents and levels
+        const int32_t nn = (int32_t)out.nodes.size();
+        out.parent_slot.assign(nn, -1);
+        std::vector<int32_t> level(nn, 0);
+        std::vector<int32_t> todo{0};
+        int32_t deepest = 0;
+        while (!todo.empty()) {
+            const int32_t id = todo.back();
+            todo.pop_back();
+            for (int s = 0; s < 2; ++s) {
+                const int32_t c = out.nodes[id].child[s];
+                if (c < 0) continue;
+                out.parent_slot[c] = id * 2 + s;
+                level[c] = level[id] + 1;
+                deepest = std::max(deepest, level[c]);
+                todo.push_back(c);
+            }
+        }
+        out.level_start.assign((size_t)deepest + 2, 0);
+        for (int32_t i = 0; i < nn; ++i) out.level_start[(size_t)(deepest - level[i]) + 1]++;
+        for (size_t k = 1; k < out.level_start.size(); ++k) out.level_start[k] += out.level_start[k - 1];
+        out.by_level.assign(nn, 0);
+        std::vector<int32_t> fill(out.level_start.begin(), out.level_start.end() - 1);
+        for (int32_t i = 0; i < nn; ++i) out.by_level[fill[(size_t)(deepest - level[i])]++] = i;
+    }
     out.prims.clear();
     out.prims.reserve(bld.order.size());
     for (int32_t i : bld.order) {

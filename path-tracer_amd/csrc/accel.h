@@ -31,6 +31,11 @@ struct Accel {
     std::vector<AccelNode> nodes; // nodes[0] is the root
     std::vector<DevOp> prims;     // primitive ops in leaf order, each carrying its FULL world -> primitive chain
     int depth = 0;
+    // for refitting on the device: where a node's own bounds are stored (parent * 2 + slot, -1 for the root) and
+    // the nodes grouped by depth, deepest level first (level_start has one more entry than there are levels)
+    std::vector<int32_t> parent_slot;
+    std::vector<int32_t> by_level;
+    std::vector<int32_t> level_start;
 };
 
 // World-space bounds of primitive op `op` (an op of flat.ops with leaf >= 0). Returns false for non-primitives.

@@ -713,6 +713,140 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Refit of the fast-mode tree for a new shutter window: the bounds of every primitive are recomputed on the device
+// (the same rules as accel.cpp's local_bounds / unxform_box) and pushed up level by level, deepest level first.
+// ------------------------------------------------------------------------------------------------------------
+struct BoxD {
+    double lo[3], hi[3];
+};
+__device__ __forceinline__ void box_clear(BoxD &b) {
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = kF64Max;
+        b.hi[k] = -kF64Max;
+    }
+}
+__device__ __forceinline__ void box_grow(BoxD &b, const BoxD &o) {
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = fmin(b.lo[k], o.lo[k]);
+        b.hi[k] = fmax(b.hi[k], o.hi[k]);
+    }
+}
+// p = R^T p' + t for the eight corners (the step maps p' = R (p - t), see xform_ray)
+__device__ __forceinline__ BoxD box_unxform(const DevXform &x, const BoxD &b) {
+    BoxD out;
+    box_clear(out);
+    for (int corner = 0; corner < 8; ++corner) {
+        const double px = (corner & 1) ? b.hi[0] : b.lo[0];
+        const double py = (corner & 2) ? b.hi[1] : b.lo[1];
+        const double pz = (corner & 4) ? b.hi[2] : b.lo[2];
+        const double p[3] = {x.c * px + x.s * pz + x.tx, py + x.ty, -x.s * px + x.c * pz + x.tz};
+        for (int k = 0; k < 3; ++k) {
+            out.lo[k] = fmin(out.lo[k], p[k]);
+            out.hi[k] = fmax(out.hi[k], p[k]);
+        }
+    }
+    return out;
+}
+__device__ bool prim_local_bounds(const SceneView &sv, const DevOp &op, double t0, double t1, BoxD &b) {
+    const int kind = op.kind & 0xff;
+    const double *d = op.d;
+    if (kind == OP_SPHERE) {
+        const double r = fabs(d[3]);
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = d[k] - r;
+            b.hi[k] = d[k] + r;
+        }
+        return true;
+    }
+    if (kind == OP_MSPHERE) { // union of the boxes at both ends of the window (src/sphere.rs:177-183)
+        const double *e = sv.leaves[op.leaf].e;
+        const double r = fabs(d[3]);
+        box_clear(b);
+        for (int w = 0; w < 2; ++w) {
+            const double f = ((w ? t1 : t0) - d[4]) / d[5];
+            for (int k = 0; k < 3; ++k) {
+                const double c = d[k] + f * e[k];
+                b.lo[k] = fmin(b.lo[k], c - r);
+                b.hi[k] = fmax(b.hi[k], c + r);
+            }
+        }
+        return true;
+    }
+    if (kind == OP_RECT) {
+        const int axis = (op.kind >> 8) & 3;
+        const int a_axis = axis == 0 ? 1 : 0, b_axis = axis == 2 ? 1 : 2;
+        b.lo[a_axis] = d[0];
+        b.hi[a_axis] = d[1];
+        b.lo[b_axis] = d[2];
+        b.hi[b_axis] = d[3];
+        b.lo[axis] = d[4] - 0.0001;
+        b.hi[axis] = d[4] + 0.0001;
+        return true;
+    }
+    if (kind == OP_BOXPRIM) {
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = d[k] - 0.0001;
+            b.hi[k] = d[k + 3] + 0.0001;
+        }
+        return true;
+    }
+    return false;
+}
+__device__ BoxD prim_world_bounds(const SceneView &sv, const DevOp &op, double t0, double t1) {
+    BoxD b;
+    box_clear(b);
+    if ((op.kind & 0xff) == OP_MEDIUM) { // the boundary primitive through the boundary's own chain
+        const DevOp bop = sv.ops[op.skip];
+        if (prim_local_bounds(sv, bop, t0, t1, b)) {
+            const int cc = (bop.kind >> 16) & 0xff;
+            for (int k = cc - 1; k >= 0; --k) b = box_unxform(sv.xforms[bop.chain_start + k], b);
+        }
+    } else {
+        (void)prim_local_bounds(sv, op, t0, t1, b);
+    }
+    const int cc = (op.kind >> 16) & 0xff; // a tree primitive carries its full world -> primitive chain
+    for (int k = cc - 1; k >= 0; --k) b = box_unxform(sv.xforms[op.chain_start + k], b);
+    return b;
+}
+__global__ __launch_bounds__(kBlock) void k_accel_refit_level(AccelNode *nodes, const DevOp *prims, SceneView sv,
+                                                              const int32_t *parent_slot, const int32_t *by_level,
+                                                              int32_t begin, int32_t end, double t0, double t1) {
+    for (int32_t idx = begin + (int32_t)(blockIdx.x * kBlock + threadIdx.x); idx < end; idx += (int32_t)(gridDim.x * kBlock)) {
+        const int32_t id = by_level[idx];
+        AccelNode &n = nodes[id];
+        BoxD whole;
+        box_clear(whole);
+        for (int s = 0; s < 2; ++s) {
+            const int32_t c = n.child[s];
+            BoxD b;
+            if (c < 0) { // leaf child: recompute from its primitives, store rounded outward
+                box_clear(b);
+                const int32_t first = (~c) >> 3, count = (~c) & 7;
+                for (int32_t k = first; k < first + count; ++k) box_grow(b, prim_world_bounds(sv, prims[k], t0, t1));
+                for (int a = 0; a < 3; ++a) {
+                    n.lo[s][a] = __double2float_rd(b.lo[a]);
+                    n.hi[s][a] = __double2float_ru(b.hi[a]);
+                }
+            }
+            for (int a = 0; a < 3; ++a) { // inner child: its level ran before this one and wrote these
+                b.lo[a] = (double)n.lo[s][a];
+                b.hi[a] = (double)n.hi[s][a];
+            }
+            box_grow(whole, b);
+        }
+        const int32_t ps = parent_slot[id];
+        if (ps >= 0) {
+            AccelNode &p = nodes[ps >> 1];
+            const int s = ps & 1;
+            for (int a = 0; a < 3; ++a) {
+                p.lo[s][a] = (float)whole.lo[a]; // exact: unions of f32 values
+                p.hi[s][a] = (float)whole.hi[a];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // shade + compaction
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz, uint32_t pid, D3 c) {
@@ -1222,7 +1356,8 @@ struct pt_ctx {
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     bool use_accel = true;         // fast mode: SAH tree for scenes that are not a short list (PTGPU_ACCEL=0 disables)
     bool accel_ok = false;
-    void *d_accel_nodes = nullptr, *d_accel_prims = nullptr;
+    void *d_accel_nodes = nullptr, *d_accel_prims = nullptr, *d_accel_parent = nullptr, *d_accel_levels = nullptr;
+    std::vector<int32_t> accel_level_start;
     int accel_depth = 0;
     void *d_ops_fused = nullptr;
     int32_t n_fused_ops = 0;
@@ -1571,7 +1706,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
-                    ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims,
+                    ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
                     ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1705,6 +1840,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
         if (build_accel(f, acc, why)) {
             if ((rc = upload(ctx, &ctx->d_accel_nodes, acc.nodes.data(), acc.nodes.size())) != PT_OK) return rc;
             if ((rc = upload(ctx, &ctx->d_accel_prims, acc.prims.data(), acc.prims.size())) != PT_OK) return rc;
+            if ((rc = upload(ctx, &ctx->d_accel_parent, acc.parent_slot.data(), acc.parent_slot.size())) != PT_OK) return rc;
+            if ((rc = upload(ctx, &ctx->d_accel_levels, acc.by_level.data(), acc.by_level.size())) != PT_OK) return rc;
+            ctx->accel_level_start = acc.level_start;
             ctx->accel_depth = acc.depth;
             ctx->accel_ok = true;
         }
@@ -1968,6 +2106,28 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_out);
     if (e != hipSuccess) return set_error(ctx, PT_ERR_HIP, hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_scene_refit(pt_ctx *ctx, double time0, double time1) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_scene_refit before pt_scene_upload");
+    if (!(time0 <= time1)) return set_error(ctx, PT_ERR_INVALID_ARG, "time0 must not exceed time1");
+    if (ctx->exact || (!ctx->accel_ok && !ctx->scan_list))
+        return set_error(ctx, PT_ERR_UNSUPPORTED_SCENE,
+                         "this context walks the host-built tree of the uploaded scene: rebuild it for the new times");
+    if (!ctx->accel_ok) return PT_OK; // primitive list: no boxes to refit
+    (void)hipSetDevice(ctx->device);
+    for (size_t l = 0; l + 1 < ctx->accel_level_start.size(); ++l) {
+        const int32_t begin = ctx->accel_level_start[l], end = ctx->accel_level_start[l + 1];
+        if (end <= begin) continue;
+        hipLaunchKernelGGL(k_accel_refit_level, dim3(grid_for(ctx, (uint32_t)(end - begin))), dim3(kBlock), 0, ctx->stream,
+                           (AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, ctx->view,
+                           (const int32_t *)ctx->d_accel_parent, (const int32_t *)ctx->d_accel_levels, begin, end, time0,
+                           time1);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 

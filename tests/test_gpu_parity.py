@@ -455,3 +455,57 @@ def test_random_rays_through_the_tree(any_ctx, name, lo, hi):
     assert np.allclose(np.abs(got["normal"][bad]), np.abs(ref["normal"][bad]), atol=1e-9)
     assert (got["material"][bad] == ref["material"][bad]).all()
     assert frac >= (0.98 if name == "final_book_two" else 0.9999), f"{name}: primitive ids agree on {frac:.6f} of rays"
+
+
+def _moving_cloud(t0, t1, seed=5):
+    """300 spheres, two thirds of them moving (src/sphere.rs:104-184), under a BVH built for the window [t0, t1]."""
+    rng = np.random.default_rng(seed)
+    s = ptgpu.Scene()
+    mat = s.lambertian(s.texture_constant((0.6, 0.6, 0.6)))
+    nodes = []
+    for k in range(300):
+        c0 = rng.uniform(0, 100, size=3)
+        if k % 3:
+            c1 = c0 + rng.uniform(-6, 6, size=3)
+            nodes.append(s.moving_sphere(tuple(c0), tuple(c1), 0.0, 1.0, 2.0, mat))
+        else:
+            nodes.append(s.sphere(tuple(c0), 2.0, mat))
+    s.set_root(s.bvh(nodes, t0, t1))
+    s.set_lights([s.rect(40, 60, 40, 60, 120, 1, mat)])
+    s.camera = ptgpu.make_camera((50, 50, -150), (50, 50, 50), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, t0, t1)
+    return s
+
+
+def test_refit_for_a_new_shutter_window(gpu_ctx, gpu_ctx_exact):
+    """pt_scene_refit: the tree uploaded for the window [0, 1] is refitted on the device for [2, 3]; rays with times in
+    the new window then find the moving spheres where the oracle finds them in a scene whose BVH the host built for
+    [2, 3]. Before the refit the old boxes hide some of them. Exact mode walks the host-built tree and says so."""
+    old, new = _moving_cloud(0.0, 1.0), _moving_cloud(2.0, 3.0)
+    rng = np.random.default_rng(17)
+    n = 60_000
+    rays = np.zeros(n, dtype=ptgpu.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-30, 130, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["time"] = rng.uniform(2.0, 3.0, size=n)
+    ref, _ = ob.intersect(new.desc(), rays)
+    gpu_ctx.upload(old)
+    stale = gpu_ctx.intersect(rays)
+    assert (stale["prim"] != ref["prim"]).mean() > 0.01  # spheres have moved out of the boxes built for [0, 1]
+    gpu_ctx.refit(2.0, 3.0)
+    got = gpu_ctx.intersect(rays)
+    frac, max_rel, both = _compare_hits(got, ref)
+    assert both.mean() > 0.05
+    assert frac >= 0.9999 and max_rel <= 1e-7
+    # back to the first window: same answers as a fresh upload
+    gpu_ctx.refit(0.0, 1.0)
+    rays["time"] = rng.uniform(0.0, 1.0, size=n)
+    ref01, _ = ob.intersect(old.desc(), rays)
+    frac, max_rel, _ = _compare_hits(gpu_ctx.intersect(rays), ref01)
+    assert frac >= 0.9999 and max_rel <= 1e-7
+    # a primitive-list scene has no boxes: nothing to do; exact mode cannot refit the reference's tree
+    gpu_ctx.upload(ptgpu.Scene.named("cornell_box", 1.0))
+    gpu_ctx.refit(2.0, 3.0)
+    gpu_ctx_exact.upload(old)
+    with pytest.raises(ptgpu.PtError):
+        gpu_ctx_exact.refit(2.0, 3.0)
