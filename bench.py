@@ -95,13 +95,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    # PTGPU_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo, for rehearsing the multi-rank code on a one-GPU box
+    # (the numbers mean nothing; RCCL refuses two ranks on one device). Never set by the driver.
+    rehearsal = os.environ.get("PTGPU_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pt = importlib.import_module("path-tracer_amd")
     tiles = importlib.import_module("path-tracer_amd.tiles")
@@ -126,7 +134,12 @@ def main():
             ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode)
             return
         ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, rows=tiles.rows_for(rank, world))
-        tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
+        if rehearsal:  # gloo gathers host tensors
+            host = image.cpu()
+            tiles.gather_rows(host, rank, world, dist)
+            image.copy_(host)
+        else:
+            tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
 
     def barrier():
         if dist is not None:
@@ -143,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=image.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else image.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
