@@ -509,3 +509,24 @@ def test_refit_for_a_new_shutter_window(gpu_ctx, gpu_ctx_exact):
     gpu_ctx_exact.upload(old)
     with pytest.raises(ptgpu.PtError):
         gpu_ctx_exact.refit(2.0, 3.0)
+
+
+def test_converged_images_agree_across_independent_seeds():
+    """The estimator, not the random stream: the device image at 4096 spp from one seed and the oracle image at
+    512 spp from another are independent estimates of the same picture. After a 4x4 box filter their difference
+    must be explained by the oracle's own noise (bar: relative RMSE 6 %, mean luminance within 1.5 %)."""
+    scene = ptgpu.Scene.named("cornell_box", 1.0)
+    w = h = 64
+    ctx = ptgpu.Context(device=0, seed=0xA11CE)
+    ctx.upload(scene)
+    ctx.render(w, h, 4096, 50)
+    gpu = ctx.readback()[..., :3].astype(np.float64)
+    ctx.close()
+    ref, _ = ob.render(scene.desc(), scene.camera, w, h, 512, 50, seed=0xB0B, threads=8)
+    ref = ref[..., :3].astype(np.float64)
+    assert np.isfinite(gpu).all() and np.isfinite(ref).all()
+    pool = lambda a: a.reshape(h // 4, 4, w // 4, 4, 3).mean(axis=(1, 3))
+    g, r = pool(gpu), pool(ref)
+    rel_rmse = np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r ** 2))
+    assert rel_rmse <= 0.06, rel_rmse
+    assert abs(gpu.mean() / ref.mean() - 1.0) <= 0.015
