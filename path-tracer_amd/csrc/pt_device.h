@@ -131,6 +131,10 @@ template <bool X> struct M {
         else return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x));
     }
     static PT_DEV double squared_length(D3 a) { return dot(a, a); }
+    static PT_DEV double sqrt_(double v) {
+        if constexpr (X) return sqrt(v);
+        else return fast_sqrt(v);
+    }
     static PT_DEV double length(D3 a) {
         if constexpr (X) return sqrt(dot(a, a));
         else return fast_sqrt(dot(a, a));
@@ -258,7 +262,7 @@ PT_DEV bool sphere_t(D3 center, double radius, D3 o, D3 d, double t_min, double 
         discriminant = __builtin_fma(-a, c, b * b);
     }
     if (discriminant > 0.0) {
-        double root = sqrt(discriminant);
+        double root = M<X>::sqrt_(discriminant);
         if constexpr (X) {
             double temp = (-b - root) / a;
             if (temp < t_max && temp > t_min) {
@@ -587,10 +591,10 @@ PT_DEV D3 onb_local(const Onb &b, D3 a) { return b.u * a.x + b.v * a.y + b.w * a
 template <bool X> PT_DEV D3 random_cosine_direction(Rng &g) { // src/material.rs:10-19
     double r1 = g.next();
     double r2 = g.next();
-    double z = sqrt(1.0 - r2);
+    double z = M<X>::sqrt_(1.0 - r2);
     double sn, cs;
     M<X>::sincos_2pi(r1, sn, cs);
-    double r2_sqrt = sqrt(r2);
+    double r2_sqrt = M<X>::sqrt_(r2);
     double x = cs * r2_sqrt;
     double y = sn * r2_sqrt;
     return d3(x, y, z);
@@ -620,10 +624,10 @@ PT_DEV D3 random_in_unit_disk(Rng &g) { // src/camera.rs:221-228
 template <bool X> PT_DEV D3 random_to_sphere(Rng &g, double radius, double distance_squared) { // src/sphere.rs:16-25
     double r1 = g.next();
     double r2 = g.next();
-    double z = 1.0 + r2 * (sqrt(1.0 - M<X>::div(radius * radius, distance_squared)) - 1.0);
+    double z = 1.0 + r2 * (M<X>::sqrt_(1.0 - M<X>::div(radius * radius, distance_squared)) - 1.0);
     double sn, cs;
     M<X>::sincos_2pi(r1, sn, cs);
-    double c = sqrt(1.0 - z * z);
+    double c = M<X>::sqrt_(1.0 - z * z);
     double x = cs * c;
     double y = sn * c;
     return d3(x, y, z);
@@ -637,7 +641,7 @@ template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3
         int which;
         D3 c = d3(l.d[0], l.d[1], l.d[2]);
         if (sphere_t<X>(c, l.d[3], origin, direction, 0.001, kF64Max, t, which)) {
-            double cos_theta_max = sqrt(1.0 - M<X>::div(l.d[3] * l.d[3], M<X>::squared_length(c - origin)));
+            double cos_theta_max = M<X>::sqrt_(1.0 - M<X>::div(l.d[3] * l.d[3], M<X>::squared_length(c - origin)));
             double solid_angle = 2.0 * kPi * (1.0 - cos_theta_max);
             return M<X>::rcp(solid_angle);
         }
@@ -656,7 +660,7 @@ template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3
             double v_sq_length = M<X>::squared_length(direction);
             double distance_sq = t * t * v_sq_length;
             D3 normal = l.axis == 0 ? d3(1.0, 0.0, 0.0) : (l.axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
-            double cosine = fabs(M<X>::div(dot(direction, normal), sqrt(v_sq_length)));
+            double cosine = fabs(M<X>::div(dot(direction, normal), M<X>::sqrt_(v_sq_length)));
             return M<X>::div(distance_sq, cosine * area);
         }
         return 0.0;
@@ -807,7 +811,7 @@ template <bool X> PT_DEV bool refract(D3 v, D3 n, double ni_over_nt, D3 &refract
     double dt = M<X>::dot(uv, n);
     double discriminant = 1.0 - ni_over_nt * ni_over_nt * (1.0 - dt * dt);
     if (discriminant > 0.0) {
-        refracted = ni_over_nt * (uv - n * dt) - n * sqrt(discriminant);
+        refracted = ni_over_nt * (uv - n * dt) - n * M<X>::sqrt_(discriminant);
         return true;
     }
     return false;

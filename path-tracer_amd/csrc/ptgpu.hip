@@ -921,7 +921,10 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
                 const D3 albedo = leaf_texture(sv, lf, rec);
                 add_radiance(lx, ly, lz, pid, beta * emissive);
-                if constexpr (X) {
+#ifndef PT_F64_WEIGHTS
+#define PT_F64_WEIGHTS 0
+#endif
+                if constexpr (X || PT_F64_WEIGHTS) {
                     Onb uvw;
                     if (lambert) uvw = onb_from_w<X>(rec.n);
                     // MixturePDF::generate, src/material.rs:427-433
@@ -944,6 +947,11 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
                     nbeta = M<X>::divs(beta * (albedo * spdf), pdf_val);
                     nd = dir;
+                    if constexpr (!X) { // fast mode: see the f32 form below
+                        const bool below = lambert && spdf == 0.0;
+                        if (below) nbeta = d3(0.0, 0.0, 0.0);
+                        dead = below && !sv.has_isotropic;
+                    }
                 } else {
                     // same estimator with the weights in f32 (see "f32 radiometry" in pt_device.h)
                     const F3 nf = to_f3(rec.n);
