@@ -146,6 +146,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and not rehearsal:
+        # communicator set-up (seconds the first time) must not land in the timed region even with --warmup 0
+        tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
     for w in range(args.warmup):
         step(w)
     ctx.stats_reset()
