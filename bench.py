@@ -198,7 +198,12 @@ def main():
             dominant = "extend" if ext_ms >= shd_ms else "shade"
             dom_ms = max(ext_ms, shd_ms)
             dom_bytes_unit = b_ray if dominant == "extend" else b_shade
-        achieved = (seg * dom_bytes_unit) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        algorithmic = seg * dom_bytes_unit
+        gen0 = fused and int(st.launches_raygen) == 0
+        if gen0:
+            # bounce 0 generates its rays in registers: its segments have no queue entry to read (48 B each)
+            algorithmic -= float(st.profiled_paths) * 48
+        achieved = algorithmic / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
         # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
         traffic = None
@@ -244,7 +249,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "avg_launch_ms": dom_ms / n_launch,
-                "algorithmic_bytes_per_launch": seg * dom_bytes_unit / n_launch,
+                "algorithmic_bytes_per_launch": algorithmic / n_launch,
                 "bytes_per_unit": dom_bytes_unit,
                 "units_per_launch": seg / n_launch,
                 "V": V,
@@ -252,6 +257,7 @@ def main():
                 "profiled_launches": n_launch,
                 "other": {
                     "fused_trace_shade": fused,
+                    "bounce0_generates_rays": gen0,
                     # the unfused two-kernel figure 204 + 32 (V + P), which prices every node / primitive visit as
                     # an HBM fetch, and the rate it would give; not used for `achieved`
                     "two_kernel_bytes_per_segment": b_ray + b_shade,

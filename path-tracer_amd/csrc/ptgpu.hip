@@ -865,12 +865,19 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
 // miss. `lf` is the hit primitive's leaf record (fields are fetched where they are used; any record when id < 0).
 // Adds the vertex's radiance to the path's accumulator and, if the path goes on, returns true with the next ray,
 // throughput and RNG draw count.
-template <bool X, bool NEED_UV>
+// FIRST: the vertex is the path's first one and nothing has initialised the path's accumulator: the vertex's
+// radiance (every branch adds at most once) is stored, zero included, instead of added.
+template <bool X, bool NEED_UV, bool FIRST = false>
 __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, D3 beta,
                                              uint64_t pkey, uint32_t pid, uint32_t &rn, double ht, int32_t id,
                                              uint32_t depth, uint32_t max_depth, uint32_t flags, double *lx, double *ly,
                                              double *lz, D3 &no, D3 &nd, D3 &nbeta) {
     bool alive = false;
+    D3 first = d3(0.0, 0.0, 0.0);
+    auto add_radiance = [&](double *ax, double *ay, double *az, uint32_t path, D3 c) {
+        if constexpr (FIRST) first = c;
+        else ::add_radiance(ax, ay, az, path, c);
+    };
     if (id < 0) {
         // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
         add_radiance(lx, ly, lz, pid, beta * 0.0);
@@ -1002,6 +1009,11 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
         if (done) add_radiance(lx, ly, lz, pid, beta * emissive); // src/trace.rs:225
         alive = !done && !dead;
         rn = g.n;
+    }
+    if constexpr (FIRST) {
+        lx[pid] = first.x;
+        ly[pid] = first.y;
+        lz[pid] = first.z;
     }
     return alive;
 }
@@ -1158,6 +1170,83 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
             qo.rn(slot) = rn;
             qo.key(slot) = pkey;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Bounce 0 of an offline pass of a fused scene: the camera sample is generated, traced and shaded in one go, so the
+// first queue (96 B per path written by raygen and read back by the first shade launch) never exists. Same chunk
+// to shard mapping as k_raygen, same camera arithmetic, same draws.
+// ------------------------------------------------------------------------------------------------------------
+template <bool NEED_UV, int FUSE>
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_first_bounce(Queue qo, QueueShape sh, uint32_t *counts,
+                                                                         SceneView sv, CameraDev cam, PassParams pp,
+                                                                         double *lx, double *ly, double *lz,
+                                                                         uint32_t flags) {
+    __shared__ ShadeLds<1> S;
+    {
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        __syncthreads();
+    }
+    uint32_t *n_out = counts + kShards;
+    const uint32_t n = pp.cpix * pp.s_count;
+    const uint32_t n_chunks = (n + kBlock - 1) / kBlock;
+    for (uint32_t j = blockIdx.x; j < n_chunks; j += gridDim.x) {
+        const uint32_t s_id = j & (sh.shards - 1);
+        const uint32_t pid = j * kBlock + threadIdx.x;
+        const bool valid = pid < n;
+        const uint32_t pc = valid ? pid : 0u; // lanes past the end trace path 0 again and are dropped
+        const uint32_t p = pc % pp.cpix, s = pc / pp.cpix;
+        const uint32_t i = pp.cx0 + p % pp.cw;
+        const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+        const uint64_t pixel = (uint64_t)jy * pp.width + i;
+        Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
+        double random = g.next(); // src/trace.rs:153-156
+        const double u = ((double)i + random) / (double)pp.width;
+        random = g.next();
+        const double v = ((double)jy + random) / (double)pp.height;
+        const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+        const D3 offset = cam.u * rd.x + cam.v * rd.y;
+        const double time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+        const D3 d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+        const D3 o = cam.origin + offset;
+        const D3 beta = d3(1.0, 1.0, 1.0);
+        uint32_t rn = g.n;
+        double ht;
+        int32_t id;
+        extend_list<FUSE == 2>(sv, sv.ops, o, d, time, g.key, 0u, 0.001, kF64Max, ht, id);
+        bool alive = false;
+        D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
+        if (valid) {
+            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
+            alive = shade_vertex<false, NEED_UV, true>(sv, S.leaves[li].l, o, d, time, beta, g.key, pid, rn, ht, id, 0u,
+                                                       pp.max_depth, flags, lx, ly, lz, no, nd, nbeta);
+        }
+        const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], S.cnt);
+        if (alive) {
+            qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
+            qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
+            qo.tm(slot) = time;
+            qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
+            qo.pid(slot) = pid;
+            qo.rn(slot) = rn;
+            qo.key(slot) = g.key;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < sh.shards) {
+        // segments of bounce 0, per shard, as k_raygen counts them (statistics only: nothing reads a first queue)
+        const uint32_t k = threadIdx.x;
+        uint32_t fill = 0;
+        if (n_chunks > k) {
+            const uint32_t mine = (n_chunks - k + sh.shards - 1) >> sh.shift;
+            fill = mine * kBlock;
+            const uint32_t last = k + (mine - 1) * sh.shards;
+            if (last == n_chunks - 1) fill -= n_chunks * kBlock - n;
+        }
+        counts[k] = fill;
     }
 }
 
@@ -1460,6 +1549,7 @@ struct pt_ctx {
     bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     uint32_t persist_factor = 1;
+    bool fuse_first = true;        // bounce 0 of an offline fused pass generates its own rays (PTGPU_FUSE_FIRST=0 disables)
     uint32_t persistent_max_paths = 1u << 23;
     bool persistent = true;        // fused scenes: one launch per pass (PTGPU_PERSISTENT=0: one launch per bounce)
     bool use_accel = true;         // fast mode: SAH tree for scenes that are not a short list (PTGPU_ACCEL=0 disables)
@@ -1695,8 +1785,23 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const bool persistent = fused && ctx->persistent && n <= ctx->persistent_max_paths;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
+    // offline passes of fused scenes with a launch per bounce: bounce 0 generates its own rays
+    const bool gen0 = fused && !persistent && !realtime && ctx->fuse_first;
     HIP_TRY(ctx, mark());
-    if (realtime)
+    if (gen0) {
+        SceneView v = ctx->view;
+        v.ops = (const DevOp *)ctx->d_ops_fused;
+        v.n_traversal_ops = ctx->n_fused_ops;
+        const bool media = ctx->view.has_medium != 0;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(g_all), dim3(kBlock), 0, st, ctx->q[1], ctx->shape, ctx->d_counts, v, ctx->cam,
+                               pp, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->render_flags);
+        };
+        if (media && ctx->need_uv) launch(k_first_bounce<true, 2>);
+        else if (media) launch(k_first_bounce<false, 2>);
+        else if (ctx->need_uv) launch(k_first_bounce<true, 1>);
+        else launch(k_first_bounce<false, 1>);
+    } else if (realtime)
         hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], gen_shape,
                            ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
     else
@@ -1745,7 +1850,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         if (!fused) launch_extend(ctx, g_d, qi, ea);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
-        launch_shade(ctx, g_d, qi, qo, d, pp.max_depth, fused);
+        if (!(gen0 && d == 0)) launch_shade(ctx, g_d, qi, qo, d, pp.max_depth, fused);
         HIP_TRY(ctx, mark());
     }
     HIP_TRY(ctx, mark());
@@ -1755,7 +1860,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
     ctx->stats.paths += n;
-    ctx->stats.launches_raygen += 1;
+    ctx->stats.launches_raygen += gen0 ? 0 : 1;
     ctx->stats.launches_extend += fused ? 0 : iters;
     ctx->stats.launches_shade += persistent ? 1 : iters;
     ctx->stats.launches_resolve += 1;
@@ -1777,7 +1882,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             return (double)ms;
         };
         size_t k = 0;
-        ctx->stats.ms_raygen += elapsed(k);
+        if (gen0) ctx->stats.ms_shade += elapsed(k); // the first launch is bounce 0 itself
+        else ctx->stats.ms_raygen += elapsed(k);
         k += 2;
         for (uint32_t d = 0; d < (persistent ? 1u : iters); ++d) {
             ctx->stats.ms_extend += elapsed(k);
@@ -1816,6 +1922,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (const char *e = std::getenv("PTGPU_LIST_MAX_LEAVES")) ctx->list_max_leaves = (int)std::strtol(e, nullptr, 10);
     if (const char *e = std::getenv("PTGPU_FUSE")) ctx->fuse = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_ACCEL")) ctx->use_accel = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("PTGPU_FUSE_FIRST")) ctx->fuse_first = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_PERSISTENT")) ctx->persistent = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_PERSISTENT_MAX_PATHS")) ctx->persistent_max_paths = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char *e = std::getenv("PTGPU_PERSIST_FACTOR")) ctx->persist_factor = (uint32_t)std::max(1l, std::strtol(e, nullptr, 10));
