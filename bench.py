@@ -199,10 +199,9 @@ def main():
             dom_ms = max(ext_ms, shd_ms)
             dom_bytes_unit = b_ray if dominant == "extend" else b_shade
         algorithmic = seg * dom_bytes_unit
+        # bounce 0 of these passes runs in k_first_bounce (camera sample + walk + shade in one launch); the library
+        # times it apart and leaves its segments out of profiled_segments, so the figures below are k_shade's alone
         gen0 = fused and int(st.launches_raygen) == 0
-        if gen0:
-            # bounce 0 generates its rays in registers: its segments have no queue entry to read (48 B each)
-            algorithmic -= float(st.profiled_paths) * 48
         achieved = algorithmic / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
         # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
@@ -264,7 +263,8 @@ def main():
                     "two_kernel_model_GBs": seg * (b_ray + b_shade) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None,
                     "extend_ms_total": None if fused else ext_ms,
                     "shade_ms_total": shd_ms,
-                    "raygen_ms_total": st.ms_raygen,
+                    "raygen_ms_total": None if gen0 else st.ms_raygen,
+                    "first_bounce_ms_total": st.ms_raygen if gen0 else None,
                     "resolve_ms_total": st.ms_resolve,
                     "extend_Mrays_s": seg / (ext_ms * 1e-3) / 1e6 if (ext_ms > 0 and not fused) else None,
                     "shade_Msegments_s": seg / (shd_ms * 1e-3) / 1e6 if shd_ms > 0 else None,

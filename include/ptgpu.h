@@ -219,7 +219,10 @@ typedef struct pt_stats {
     uint64_t prim_tests;       /* primitives tested  (needs PT_CFG_COUNT_TRAVERSAL) */
     uint64_t nan_pixels;       /* pixels whose last written colour has a NaN channel */
     uint64_t launches_raygen, launches_extend, launches_shade, launches_resolve;
-    double ms_raygen, ms_extend, ms_shade, ms_resolve; /* summed HIP-event time of profiled launches */
+    double ms_raygen, ms_extend, ms_shade, ms_resolve; /* summed HIP-event time of profiled launches; when an offline
+                                                        * pass's bounce 0 makes its own rays (launches_raygen == 0) that
+                                                        * launch is timed under ms_raygen and its segments are not in
+                                                        * profiled_segments */
     uint64_t profiled_segments;/* segments processed by the profiled extend/shade launches */
     uint64_t profiled_paths;   /* paths processed by the profiled raygen/resolve launches */
     uint64_t profiled_passes;  /* profiled raygen (= resolve) launches */

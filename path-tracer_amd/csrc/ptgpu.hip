@@ -1862,7 +1862,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     ctx->stats.paths += n;
     ctx->stats.launches_raygen += gen0 ? 0 : 1;
     ctx->stats.launches_extend += fused ? 0 : iters;
-    ctx->stats.launches_shade += persistent ? 1 : iters;
+    ctx->stats.launches_shade += persistent ? 1 : (gen0 ? iters - 1 : iters);
     ctx->stats.launches_resolve += 1;
     if (profile || (read_counts && !persistent)) { // the one-launch form sizes no grids from the counts
         ctx->h_shard_counts.resize((size_t)(iters + 1) * kShards);
@@ -1882,8 +1882,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             return (double)ms;
         };
         size_t k = 0;
-        if (gen0) ctx->stats.ms_shade += elapsed(k); // the first launch is bounce 0 itself
-        else ctx->stats.ms_raygen += elapsed(k);
+        ctx->stats.ms_raygen += elapsed(k); // with gen0 this launch is k_first_bounce: ray generation AND bounce 0
         k += 2;
         for (uint32_t d = 0; d < (persistent ? 1u : iters); ++d) {
             ctx->stats.ms_extend += elapsed(k);
@@ -1891,11 +1890,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             ctx->stats.ms_shade += elapsed(k);
             k += 2;
         }
-        for (uint32_t d = 0; d < iters; ++d) ctx->stats.profiled_segments += ctx->h_counts[d];
+        // segments of the launches timed as extend / shade (bounce 0 belongs to k_first_bounce when it ran)
+        for (uint32_t d = gen0 ? 1u : 0u; d < iters; ++d) ctx->stats.profiled_segments += ctx->h_counts[d];
         ctx->stats.ms_resolve += elapsed(k);
         ctx->stats.profiled_paths += n;
         ctx->stats.profiled_passes += 1;
-        ctx->stats.profiled_bounce_launches += persistent ? 1 : iters;
+        ctx->stats.profiled_bounce_launches += persistent ? 1 : (gen0 ? iters - 1 : iters);
     }
     return PT_OK;
 }
