@@ -712,6 +712,119 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q,
     }
 }
 
+// The same traversal with the wave kept full. Rays of one wave need very different numbers of steps (a ray that
+// leaves the scene at once next to one that grazes a thousand boxes), so in the form above most lanes of a wave sit
+// idle for most of its life. Here a wave owns a run of the queue and works as a pool of 64 ray slots: a lane whose
+// ray is done writes its result and, once enough lanes are free, the free lanes take the next rays of the run
+// (ballot + prefix count, no atomics: the run belongs to this wave alone). Each round first steps every lane down
+// through inner nodes until it stands on a leaf (or is done), then tests the leaves, so both loops run with most
+// lanes active. Runs are dealt shard by shard; any grid is correct.
+template <bool MEDIA>
+__global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Queue q, SceneView sv, const AccelNode *nodes,
+                                                                            const DevOp *prims, ExtendArgs a,
+                                                                            uint32_t tuning) {
+    __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
+    const uint32_t refill_at = tuning & 0xffu, inner_min = tuning >> 8;
+    constexpr int32_t kDone = INT32_MIN;             // never a leaf reference (those are ~((first << 3) | count))
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    // virtual waves: a multiple of the shard count, at least one per shard; wave w serves w, w + n_waves, ...
+    const uint32_t per_shard = (n_waves + a.sh.shards - 1) >> a.sh.shift;
+    const uint32_t n_virtual = per_shard << a.sh.shift;
+    uint32_t v_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
+    uint32_t cur = 0, end = 0, base = 0; // the run being served: slots [cur, end) of the shard starting at `base`
+    bool has = false;                    // this lane holds a ray in flight
+    uint32_t my_i = 0;
+    D3 o = d3(0, 0, 0), d = o, inv = o;
+    double time = 0.0, closest = 0.0;
+    uint64_t pkey = 0;
+    int32_t best = -1, node = kDone;
+    int sp = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (cur >= end) {
+                if (v_next < n_virtual) { // next run of this wave
+                    const uint32_t s_id = v_next & (a.sh.shards - 1), k = v_next >> a.sh.shift;
+                    const uint32_t count = shard_count(a.counts, s_id);
+                    const uint32_t per = (((count + per_shard - 1) / per_shard) + 63u) & ~63u;
+                    cur = min(k * per, count);
+                    end = min(cur + per, count);
+                    base = s_id * a.sh.shard_cap;
+                    v_next += n_waves;
+                    continue;
+                }
+                if (n_idle == 64) break; // nothing in flight and nothing left to take
+            } else if (n_idle >= refill_at || n_idle == 64) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!has && cur + rank < end) {
+                    my_i = base + cur + rank;
+                    o = d3(q.ox(my_i), q.oy(my_i), q.oz(my_i));
+                    d = d3(q.dx(my_i), q.dy(my_i), q.dz(my_i));
+                    time = q.tm(my_i);
+                    if (MEDIA) pkey = (a.key_mode == 0) ? q.key(my_i) : intersect_key(a.medium_seed, my_i);
+                    inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+                    closest = a.t_max;
+                    best = -1;
+                    sp = 0;
+                    // rays with a NaN or infinite component are not traced (see k_extend_accel)
+                    const double probe = (o.x + o.y + o.z) + (d.x + d.y + d.z);
+                    node = (probe == probe && fabs(probe) <= kF64Max) ? 0 : kDone;
+                    has = true;
+                }
+                cur += n_idle;
+            }
+        }
+        // down through inner nodes, nearer child first, the farther one on the stack, for as long as at least
+        // `inner_min` lanes are still on inner nodes
+        for (;;) {
+            if (has && node >= 0) {
+                const AccelNode &n = nodes[node];
+                double t0, t1;
+                const bool h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
+                const bool h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
+                const int32_t c0 = n.child[0], c1 = n.child[1];
+                if (h0 && h1) {
+                    const bool first0 = t0 <= t1;
+                    stack[sp++][threadIdx.x] = first0 ? c1 : c0;
+                    node = first0 ? c0 : c1;
+                } else if (h0 || h1) {
+                    node = h0 ? c0 : c1;
+                } else {
+                    node = sp ? stack[--sp][threadIdx.x] : kDone;
+                }
+            }
+            const uint32_t n_inner = (uint32_t)__popcll(__ballot(has && node >= 0));
+            if (n_inner == 0 || n_inner < inner_min) break;
+        }
+        // the primitives of a leaf
+        if (has && node < 0 && node != kDone) {
+            const int32_t ref = ~node;
+            const int32_t first = ref >> 3, count = ref & 7;
+            for (int32_t k = first; k < first + count; ++k) {
+                const DevOp op = prims[k];
+                double t = 0.0;
+                int sub = 0;
+                bool hit;
+                if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
+                    hit = medium_hit<false>(sv, op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t);
+                else hit = prim_hit<false>(sv, op, o, d, inv, time, a.t_min, closest, t, sub);
+                if (hit) {
+                    closest = t;
+                    best = op.leaf | (sub << 28);
+                }
+            }
+            node = sp ? stack[--sp][threadIdx.x] : kDone;
+        }
+        if (has && node == kDone) {
+            a.hit_t[my_i] = closest;
+            a.hit_id[my_i] = best;
+            has = false;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Refit of the fast-mode tree for a new shutter window: the bounds of every primitive are recomputed on the device
 // (the same rules as accel.cpp's local_bounds / unxform_box) and pushed up level by level, deepest level first.
@@ -1549,6 +1662,12 @@ struct pt_ctx {
     bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     uint32_t persist_factor = 1;
+    bool accel_pool = true;      // SAH traversal with lane refill (k_extend_accel_pool) instead of a ray per thread
+    uint32_t accel_refill = 24;  // free lanes at which a wave takes new rays
+    uint32_t accel_pool_from = 0; // first bounce traced by the pool form
+    bool accel_pool_from_set = false;
+    uint32_t accel_grid = 2;     // workgroups per resident slot
+    uint32_t accel_inner = 24;   // lanes on inner nodes below which a wave turns to its leaves
     bool fuse_first = true;        // bounce 0 of an offline fused pass generates its own rays (PTGPU_FUSE_FIRST=0 disables)
     uint32_t persistent_max_paths = 1u << 23;
     bool persistent = true;        // fused scenes: one launch per pass (PTGPU_PERSISTENT=0: one launch per bounce)
@@ -1687,7 +1806,11 @@ D3 hunit(D3 a) {
 
 template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
-    if (!X && ctx->accel_ok && a.counters == nullptr) {
+    if (!X && ctx->accel_ok && a.counters == nullptr && ctx->accel_pool && !(ctx->accel_pool_from > a.depth && a.key_mode == 0)) {
+        grid = std::min(grid, ctx->n_cu * (MEDIA ? 4 : 5) * (int)ctx->accel_grid); // what is resident at once
+        hipLaunchKernelGGL((k_extend_accel_pool<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
+                           (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a, ctx->accel_refill | (ctx->accel_inner << 8));
+    } else if (!X && ctx->accel_ok && a.counters == nullptr) {
         hipLaunchKernelGGL((k_extend_accel<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
                            (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a);
     } else if (!X && !FRAMES && ctx->use_scan && ctx->scan_list && ctx->fuse_ok && ctx->fuse && a.counters == nullptr) {
@@ -1925,6 +2048,14 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (const char *e = std::getenv("PTGPU_FUSE_FIRST")) ctx->fuse_first = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_PERSISTENT")) ctx->persistent = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_PERSISTENT_MAX_PATHS")) ctx->persistent_max_paths = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char *e = std::getenv("PTGPU_ACCEL_POOL")) ctx->accel_pool = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("PTGPU_ACCEL_POOL_FROM")) {
+        ctx->accel_pool_from = (uint32_t)std::max(0l, std::strtol(e, nullptr, 10));
+        ctx->accel_pool_from_set = true;
+    }
+    if (const char *e = std::getenv("PTGPU_ACCEL_GRID")) ctx->accel_grid = (uint32_t)std::min(8l, std::max(1l, std::strtol(e, nullptr, 10)));
+    if (const char *e = std::getenv("PTGPU_ACCEL_INNER")) ctx->accel_inner = (uint32_t)std::min(65l, std::max(1l, std::strtol(e, nullptr, 10)));
+    if (const char *e = std::getenv("PTGPU_ACCEL_REFILL")) ctx->accel_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_PERSIST_FACTOR")) ctx->persist_factor = (uint32_t)std::max(1l, std::strtol(e, nullptr, 10));
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;
@@ -2092,6 +2223,10 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
             ctx->accel_level_start = acc.level_start;
             ctx->accel_depth = acc.depth;
             ctx->accel_ok = true;
+            // Camera rays through a small tree take similar numbers of steps, and a ray per thread is then the
+            // faster form (measured on ~500 spheres: +9 % on the render); bigger trees gain from the lane pool at
+            // every bounce.
+            if (!ctx->accel_pool_from_set) ctx->accel_pool_from = acc.nodes.size() <= 1024 ? 1u : 0u;
         }
     }
     ctx->profile.clear();

@@ -164,3 +164,35 @@ def test_pass_forms_give_the_same_image():
     assert st.launches_raygen == 0 and st.launches_shade > 1  # bounce 0 made its own rays, a launch per bounce
     assert np.array_equal(a, b, equal_nan=True)
     assert np.isfinite(a[..., :3]).all() and a[..., :3].mean() > 0.05
+
+
+@pytest.mark.parametrize("name,param", [("sphere_cloud", 50000), ("final_book_two", 0)])
+def test_tree_traversal_forms_agree(name, param):
+    """Fast mode walks the SAH tree either with one ray per thread or with waves that refill their free lanes from a
+    run of the queue. Both test the same primitives with the same arithmetic, so ids and distances are identical,
+    whatever the refill thresholds and however the rays are dealt to the waves (ragged batch sizes, one shard)."""
+    scene = ptgpu.Scene.named(name, 1.0, param=param)
+    primary, secondary = _rays(scene, 192, 160)
+    batches = [primary, secondary, secondary[:4097], primary[:63], primary[:1]]
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            ctx = _ctx(max_paths_in_flight=1 << 16)
+            ctx.upload(scene)
+            out = [ctx.intersect(b, medium_seed=5) for b in batches]
+            ctx.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return out
+
+    base = run({"PTGPU_ACCEL_POOL": "0"})
+    for env in ({}, {"PTGPU_ACCEL_REFILL": "1", "PTGPU_ACCEL_INNER": "1"}, {"PTGPU_ACCEL_REFILL": "64", "PTGPU_ACCEL_INNER": "65"},
+                {"PTGPU_SHARDS": "1", "PTGPU_ACCEL_GRID": "1"}, {"PTGPU_SHARDS": "64"}):
+        got = run(env)
+        for a, b in zip(base, got):
+            assert np.array_equal(a["prim"], b["prim"]), env
+            assert np.array_equal(a["t"], b["t"], equal_nan=True), env
+    assert (base[0]["prim"] >= 0).mean() > 0.1
