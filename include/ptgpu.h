@@ -332,6 +332,18 @@ int pt_scene_refit(pt_ctx *ctx, double time0, double time1);
  * every primitive in exactly one leaf, child boxes enclose their subtrees, depth within the traversal stack. */
 int pt_scene_accel_info(const pt_scene_desc *scene, int32_t *n_nodes, int32_t *n_prims, int32_t *depth);
 
+/* Replaces BvhNode::from_list (src/bvh.rs:13-69) for a scene that is already on the device: BUILDS the fast-mode tree
+ * there instead of refitting the host-built one. The primitives' bounds for the shutter window [time0, time1] and
+ * 63-bit Morton codes of their centres are computed on the device and the primitives are sorted along the curve
+ * (radix sort); the tree is then grown level by level, one launch per level, every node splitting its run of the
+ * curve where the highest differing code bit flips (in the middle once the remaining depth budget only fits a
+ * balanced subtree, which bounds the traversal stack), leaves of at most four primitives; the boxes are fitted
+ * bottom up, one launch per level. The host only reads back one node counter per level to size the next launch.
+ * Hits are those of any other tree over the same primitives (exact ties aside). For scenes whose geometry moves a
+ * lot between windows, where a refit would keep a stale topology. Same preconditions and errors as pt_scene_refit. */
+int pt_scene_build_device(pt_ctx *ctx, double time0, double time1);
+
+
 /* Reinhard(1.5) + sqrt gamma + u8 conversion with the row flip of the PPM writers
  * (src/trace.rs:236-242, src/lib.rs:330-340,613-640). rgb8_out is width*height*3, top row first. */
 int pt_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8_out);

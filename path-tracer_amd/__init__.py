@@ -223,7 +223,8 @@ EXPORTS = [
     "pt_scene_flip_normals", "pt_scene_translate", "pt_scene_rotate_y", "pt_scene_constant_medium", "pt_scene_list",
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
     "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
-    "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_abi_version",
+    "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_scene_build_device",
+    "pt_abi_version",
 ]
 
 _vp = C.c_void_p
@@ -288,6 +289,7 @@ _sig("pt_session_free", None, _vp)
 _sig("pt_session_frame", C.c_int, _vp, C.POINTER(UserInput), C.c_double, C.POINTER(FrameInfo))
 _sig("pt_scene_accel_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p)
 _sig("pt_scene_refit", C.c_int, _vp, C.c_double, C.c_double)
+_sig("pt_scene_build_device", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_abi_version", C.c_uint32)
 
 
@@ -475,6 +477,10 @@ class Context:
         """Refits the fast-mode tree for the shutter window [time0, time1] (pt_scene_refit)."""
         self._check(lib.pt_scene_refit(self._h, float(time0), float(time1)), "pt_scene_refit")
 
+    def build_tree_on_device(self, time0, time1):
+        """Builds the fast-mode tree on the device for the shutter window [time0, time1] (pt_scene_build_device)."""
+        self._check(lib.pt_scene_build_device(self._h, float(time0), float(time1)), "pt_scene_build_device")
+
     def reset(self):
         self._check(lib.pt_accum_reset(self._h), "pt_accum_reset")
 
@@ -590,3 +596,4 @@ def write_ppm(path, rgb8):
     with open(path, "wb") as f:
         f.write(f"P6 {w} {h} 255\n".encode())
         f.write(np.ascontiguousarray(rgb8, dtype=np.uint8).tobytes())
+

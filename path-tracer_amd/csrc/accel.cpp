@@ -272,6 +272,34 @@ bool accel_prim_bounds(const FlatScene &flat, const DevOp &op, double lo[3], dou
     return true;
 }
 
+// Parents and levels of a finished node array: where each node's own bounds are stored in its parent, and the nodes
+// grouped by depth, deepest level first, for the bottom-up refit.
+void accel_link_levels(Accel &out) {
+    const int32_t nn = (int32_t)out.nodes.size();
+    out.parent_slot.assign(nn, -1);
+    std::vector<int32_t> level(nn, 0);
+    std::vector<int32_t> todo{0};
+    int32_t deepest = 0;
+    while (!todo.empty()) {
+        const int32_t id = todo.back();
+        todo.pop_back();
+        for (int s = 0; s < 2; ++s) {
+            const int32_t c = out.nodes[id].child[s];
+            if (c < 0) continue;
+            out.parent_slot[c] = id * 2 + s;
+            level[c] = level[id] + 1;
+            deepest = std::max(deepest, level[c]);
+            todo.push_back(c);
+        }
+    }
+    out.level_start.assign((size_t)deepest + 2, 0);
+    for (int32_t i = 0; i < nn; ++i) out.level_start[(size_t)(deepest - level[i]) + 1]++;
+    for (size_t k = 1; k < out.level_start.size(); ++k) out.level_start[k] += out.level_start[k - 1];
+    out.by_level.assign(nn, 0);
+    std::vector<int32_t> fill(out.level_start.begin(), out.level_start.end() - 1);
+    for (int32_t i = 0; i < nn; ++i) out.by_level[fill[(size_t)(deepest - level[i])]++] = i;
+}
+
 bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
     Builder bld;
     for (int32_t i = 0; i < flat.n_traversal_ops; ++i) {
@@ -306,31 +334,7 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
     }
     out.nodes.swap(bld.nodes);
     out.depth = bld.max_depth;
-    { // parents and levels
-        const int32_t nn = (int32_t)out.nodes.size();
-        out.parent_slot.assign(nn, -1);
-        std::vector<int32_t> level(nn, 0);
-        std::vector<int32_t> todo{0};
-        int32_t deepest = 0;
-        while (!todo.empty()) {
-            const int32_t id = todo.back();
-            todo.pop_back();
-            for (int s = 0; s < 2; ++s) {
-                const int32_t c = out.nodes[id].child[s];
-                if (c < 0) continue;
-                out.parent_slot[c] = id * 2 + s;
-                level[c] = level[id] + 1;
-                deepest = std::max(deepest, level[c]);
-                todo.push_back(c);
-            }
-        }
-        out.level_start.assign((size_t)deepest + 2, 0);
-        for (int32_t i = 0; i < nn; ++i) out.level_start[(size_t)(deepest - level[i]) + 1]++;
-        for (size_t k = 1; k < out.level_start.size(); ++k) out.level_start[k] += out.level_start[k - 1];
-        out.by_level.assign(nn, 0);
-        std::vector<int32_t> fill(out.level_start.begin(), out.level_start.end() - 1);
-        for (int32_t i = 0; i < nn; ++i) out.by_level[fill[(size_t)(deepest - level[i])]++] = i;
-    }
+    accel_link_levels(out);
     out.prims.clear();
     out.prims.reserve(bld.order.size());
     for (int32_t i : bld.order) {

@@ -45,4 +45,7 @@ bool accel_prim_bounds(const FlatScene &flat, const DevOp &op, double lo[3], dou
 // no primitives or the tree would be deeper than kAccelMaxDepth.
 bool build_accel(const FlatScene &flat, Accel &out, std::string &error);
 
+// Fills parent_slot / by_level / level_start from nodes.
+void accel_link_levels(Accel &out);
+
 } // namespace ptdev

@@ -9,6 +9,7 @@
 //   resolve  per-pixel mean in sample order -> f32 RGBA image (src/trace.rs:166-182)
 // One pass traces `paths in flight` paths to completion: raygen, then (extend, shade) once per bounce.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(kBlock) void k_accel_refit_level(AccelNode *nodes, 
                                                               const int32_t *parent_slot, const int32_t *by_level,
                                                               int32_t begin, int32_t end, double t0, double t1) {
     for (int32_t idx = begin + (int32_t)(blockIdx.x * kBlock + threadIdx.x); idx < end; idx += (int32_t)(gridDim.x * kBlock)) {
-        const int32_t id = by_level[idx];
+        const int32_t id = by_level ? by_level[idx] : idx; // a device-built tree numbers its nodes level by level
         AccelNode &n = nodes[id];
         BoxD whole;
         box_clear(whole);
@@ -955,6 +956,87 @@ __global__ __launch_bounds__(kBlock) void k_accel_refit_level(AccelNode *nodes, 
                 p.lo[s][a] = (float)whole.lo[a]; // exact: unions of f32 values
                 p.hi[s][a] = (float)whole.hi[a];
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Tree build on the device (pt_scene_build_device): Morton codes of the primitives' centres, a radix sort, a gather
+// of the 64-B primitive records into curve order; the boxes then come from the refit kernels above.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t morton_spread21(uint64_t v) { // bit k of a 21-bit value moves to bit 3 k
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+__global__ __launch_bounds__(kBlock) void k_accel_prim_codes(const DevOp *prims, SceneView sv, int32_t n, double t0,
+                                                             double t1, D3 lo, D3 scale, uint64_t *keys, uint32_t *vals) {
+    for (int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x); k < n; k += (int32_t)(gridDim.x * kBlock)) {
+        const BoxD b = prim_world_bounds(sv, prims[k], t0, t1);
+        uint64_t code = 0;
+        const double s[3] = {scale.x, scale.y, scale.z}, l[3] = {lo.x, lo.y, lo.z};
+        for (int a = 0; a < 3; ++a) {
+            const double q = (0.5 * (b.lo[a] + b.hi[a]) - l[a]) * s[a]; // [0, 2^21) across the scene's box
+            const uint64_t cell = (uint64_t)fmin(fmax(q, 0.0), 2097151.0);
+            code |= morton_spread21(cell) << a;
+        }
+        keys[k] = code;
+        vals[k] = (uint32_t)k;
+    }
+}
+// out[j] = in[order[j]], 16 bytes per thread (a record is four of them)
+__global__ __launch_bounds__(kBlock) void k_accel_gather_prims(const DevOp *in, const uint32_t *order, DevOp *out, int32_t n) {
+    const int64_t total = (int64_t)n * 4;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int32_t j = (int32_t)(t >> 2), part = (int32_t)(t & 3);
+        ((uint4 *)(out + j))[part] = ((const uint4 *)(in + order[j]))[part];
+    }
+}
+
+struct BuildRange {
+    int32_t first, n; // the primitives, in curve order, below a node
+};
+// One level of the tree: every node of the level splits its run of the sorted codes and creates its children. A child
+// of at most four primitives is a leaf reference; a larger one becomes a node of the next level, numbered by an
+// atomic counter (so a level's nodes are consecutive). The split is where the highest differing code bit flips, as
+// long as a balanced subtree below it would still fit the traversal stack; after that, and between equal codes, it
+// is the middle of the run.
+__global__ __launch_bounds__(kBlock) void k_accel_build_level(const uint64_t *keys, AccelNode *nodes, int32_t *parent_slot,
+                                                              BuildRange *ranges, int32_t begin, int32_t end,
+                                                              int32_t level, int32_t *next_id) {
+    for (int32_t j = begin + (int32_t)(blockIdx.x * kBlock + threadIdx.x); j < end; j += (int32_t)(gridDim.x * kBlock)) {
+        const int32_t first = ranges[j].first, n = ranges[j].n, last = first + n - 1;
+        int log2n = 0;
+        while ((1 << log2n) < n) ++log2n;
+        const uint64_t a = keys[first], b = keys[last];
+        int32_t split = first + n / 2;
+        if (a != b && level + log2n + 2 < kAccelMaxDepth - 2) {
+            const int bit = 63 - __clzll((long long)(a ^ b));
+            int32_t lo = first, hi = last; // bit clear at lo, set at hi
+            while (hi - lo > 1) {
+                const int32_t mid = lo + (hi - lo) / 2;
+                if ((keys[mid] >> bit) & 1ull) hi = mid;
+                else lo = mid;
+            }
+            split = hi;
+        }
+        AccelNode &node = nodes[j];
+        node.pad[0] = node.pad[1] = 0;
+        for (int s = 0; s < 2; ++s) {
+            const int32_t cf = s ? split : first, cn = s ? first + n - split : split - first;
+            int32_t ref;
+            if (cn <= 4) {
+                ref = ~((cf << 3) | cn);
+            } else {
+                ref = atomicAdd(next_id, 1);
+                ranges[ref] = BuildRange{cf, cn};
+                parent_slot[ref] = j * 2 + s;
+            }
+            node.child[s] = ref;
         }
     }
 }
@@ -1674,8 +1756,9 @@ struct pt_ctx {
     bool use_accel = true;         // fast mode: SAH tree for scenes that are not a short list (PTGPU_ACCEL=0 disables)
     bool accel_ok = false;
     void *d_accel_nodes = nullptr, *d_accel_prims = nullptr, *d_accel_parent = nullptr, *d_accel_levels = nullptr;
-    std::vector<int32_t> accel_level_start;
+    std::vector<std::pair<int32_t, int32_t>> accel_levels; // refit order (deepest level first): index ranges of d_accel_levels, or node id ranges when that is null
     int accel_depth = 0;
+    int32_t n_accel_prims = 0;
     void *d_ops_fused = nullptr;
     int32_t n_fused_ops = 0;
     std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
@@ -2220,8 +2303,11 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
             if ((rc = upload(ctx, &ctx->d_accel_prims, acc.prims.data(), acc.prims.size())) != PT_OK) return rc;
             if ((rc = upload(ctx, &ctx->d_accel_parent, acc.parent_slot.data(), acc.parent_slot.size())) != PT_OK) return rc;
             if ((rc = upload(ctx, &ctx->d_accel_levels, acc.by_level.data(), acc.by_level.size())) != PT_OK) return rc;
-            ctx->accel_level_start = acc.level_start;
+            ctx->accel_levels.clear();
+            for (size_t l = 0; l + 1 < acc.level_start.size(); ++l)
+                ctx->accel_levels.emplace_back(acc.level_start[l], acc.level_start[l + 1]);
             ctx->accel_depth = acc.depth;
+            ctx->n_accel_prims = (int32_t)acc.prims.size();
             ctx->accel_ok = true;
             // Camera rays through a small tree take similar numbers of steps, and a ray per thread is then the
             // faster form (measured on ~500 spheres: +9 % on the render); bigger trees gain from the lane pool at
@@ -2491,6 +2577,21 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     return PT_OK;
 }
 
+// Bounds of every primitive for [time0, time1], pushed up the tree one launch per level, deepest level first.
+static int refit_levels(pt_ctx *ctx, double time0, double time1) {
+    for (const auto &lv : ctx->accel_levels) {
+        const int32_t begin = lv.first, end = lv.second;
+        if (end <= begin) continue;
+        hipLaunchKernelGGL(k_accel_refit_level, dim3(grid_for(ctx, (uint32_t)(end - begin))), dim3(kBlock), 0, ctx->stream,
+                           (AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, ctx->view,
+                           (const int32_t *)ctx->d_accel_parent, (const int32_t *)ctx->d_accel_levels, begin, end, time0,
+                           time1);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 int pt_scene_refit(pt_ctx *ctx, double time0, double time1) {
     if (!ctx) return PT_ERR_INVALID_ARG;
     if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_scene_refit before pt_scene_upload");
@@ -2500,16 +2601,95 @@ int pt_scene_refit(pt_ctx *ctx, double time0, double time1) {
                          "this context walks the host-built tree of the uploaded scene: rebuild it for the new times");
     if (!ctx->accel_ok) return PT_OK; // primitive list: no boxes to refit
     (void)hipSetDevice(ctx->device);
-    for (size_t l = 0; l + 1 < ctx->accel_level_start.size(); ++l) {
-        const int32_t begin = ctx->accel_level_start[l], end = ctx->accel_level_start[l + 1];
-        if (end <= begin) continue;
-        hipLaunchKernelGGL(k_accel_refit_level, dim3(grid_for(ctx, (uint32_t)(end - begin))), dim3(kBlock), 0, ctx->stream,
-                           (AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, ctx->view,
-                           (const int32_t *)ctx->d_accel_parent, (const int32_t *)ctx->d_accel_levels, begin, end, time0,
-                           time1);
+    return refit_levels(ctx, time0, time1);
+}
+
+int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_scene_build_device before pt_scene_upload");
+    if (!(time0 <= time1)) return set_error(ctx, PT_ERR_INVALID_ARG, "time0 must not exceed time1");
+    if (ctx->exact || (!ctx->accel_ok && !ctx->scan_list))
+        return set_error(ctx, PT_ERR_UNSUPPORTED_SCENE,
+                         "this context walks the host-built tree of the uploaded scene: rebuild it for the new times");
+    if (!ctx->accel_ok) return PT_OK; // primitive list: no tree
+    (void)hipSetDevice(ctx->device);
+    const int32_t n = ctx->n_accel_prims;
+    if (n < 2) return set_error(ctx, PT_ERR_UNSUPPORTED_SCENE, "fewer than two primitives");
+    // the scene's box for the new window: fit the current tree and read its root
+    int rc = refit_levels(ctx, time0, time1);
+    if (rc != PT_OK) return rc;
+    AccelNode root;
+    HIP_TRY(ctx, hipMemcpyAsync(&root, ctx->d_accel_nodes, sizeof(root), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double lo[3], scale[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = std::min((double)root.lo[0][a], (double)root.lo[1][a]);
+        const double extent = std::max((double)root.hi[0][a], (double)root.hi[1][a]) - lo[a];
+        scale[a] = extent > 0.0 ? 2097152.0 / extent : 0.0;
+    }
+    // scratch and the new arrays; whatever is still held here when the function returns is freed
+    struct Held {
+        void *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *temp = nullptr, *ranges = nullptr, *counter = nullptr;
+        void *prims = nullptr, *nodes = nullptr, *parent = nullptr;
+        ~Held() {
+            for (void *p : {keys[0], keys[1], vals[0], vals[1], temp, ranges, counter, prims, nodes, parent})
+                if (p) (void)hipFree(p);
+        }
+    } h;
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(ctx, hipMalloc(&h.keys[k], (size_t)n * sizeof(uint64_t)));
+        HIP_TRY(ctx, hipMalloc(&h.vals[k], (size_t)n * sizeof(uint32_t)));
+    }
+    HIP_TRY(ctx, hipMalloc(&h.prims, (size_t)n * sizeof(DevOp)));
+    // at most n - 1 nodes (every leaf a single primitive)
+    HIP_TRY(ctx, hipMalloc(&h.nodes, (size_t)n * sizeof(AccelNode)));
+    HIP_TRY(ctx, hipMalloc(&h.parent, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&h.ranges, (size_t)n * sizeof(BuildRange)));
+    HIP_TRY(ctx, hipMalloc(&h.counter, sizeof(int32_t)));
+    hipLaunchKernelGGL(k_accel_prim_codes, dim3(grid_for(ctx, (uint32_t)n)), dim3(kBlock), 0, ctx->stream,
+                       (const DevOp *)ctx->d_accel_prims, ctx->view, n, time0, time1, D3{lo[0], lo[1], lo[2]},
+                       D3{scale[0], scale[1], scale[2]}, (uint64_t *)h.keys[0], (uint32_t *)h.vals[0]);
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint64_t *)h.keys[0], (uint64_t *)h.keys[1],
+                                                    (const uint32_t *)h.vals[0], (uint32_t *)h.vals[1], n, 0, 63, ctx->stream));
+    HIP_TRY(ctx, hipMalloc(&h.temp, std::max<size_t>(temp_bytes, 16)));
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(h.temp, temp_bytes, (const uint64_t *)h.keys[0], (uint64_t *)h.keys[1],
+                                                    (const uint32_t *)h.vals[0], (uint32_t *)h.vals[1], n, 0, 63, ctx->stream));
+    hipLaunchKernelGGL(k_accel_gather_prims, dim3(grid_for(ctx, (uint64_t)n * 4)), dim3(kBlock), 0, ctx->stream,
+                       (const DevOp *)ctx->d_accel_prims, (const uint32_t *)h.vals[1], (DevOp *)h.prims, n);
+    // the tree, level by level: node 0 is the root over the whole curve
+    const BuildRange whole{0, n};
+    const int32_t root_parent = -1, one = 1;
+    HIP_TRY(ctx, hipMemcpyAsync(h.ranges, &whole, sizeof(whole), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h.parent, &root_parent, sizeof(root_parent), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h.counter, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<std::pair<int32_t, int32_t>> levels;
+    int32_t begin = 0, end = 1;
+    for (int32_t level = 0; end > begin; ++level) {
+        if (level >= kAccelMaxDepth) return set_error(ctx, PT_ERR_HIP, "device tree build exceeded its depth bound");
+        levels.emplace_back(begin, end);
+        hipLaunchKernelGGL(k_accel_build_level, dim3(grid_for(ctx, (uint32_t)(end - begin))), dim3(kBlock), 0, ctx->stream,
+                           (const uint64_t *)h.keys[1], (AccelNode *)h.nodes, (int32_t *)h.parent, (BuildRange *)h.ranges,
+                           begin, end, level, (int32_t *)h.counter);
+        int32_t next = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&next, h.counter, sizeof(next), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        begin = end;
+        end = next;
+        if (end > n) return set_error(ctx, PT_ERR_HIP, "device tree build made more nodes than primitives");
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // hand the new arrays to the context (the old ones go with `h`) and fit the boxes
+    std::swap(ctx->d_accel_prims, h.prims);
+    std::swap(ctx->d_accel_nodes, h.nodes);
+    std::swap(ctx->d_accel_parent, h.parent);
+    if (ctx->d_accel_levels) (void)hipFree(ctx->d_accel_levels);
+    ctx->d_accel_levels = nullptr; // node ids are level-ordered already
+    ctx->accel_levels.assign(levels.rbegin(), levels.rend());
+    ctx->accel_depth = (int)levels.size();
+    ctx->accel_ok = false; // until the boxes are in
+    if ((rc = refit_levels(ctx, time0, time1)) != PT_OK) return rc;
+    ctx->accel_ok = true;
     return PT_OK;
 }
 

@@ -511,6 +511,52 @@ def test_refit_for_a_new_shutter_window(gpu_ctx, gpu_ctx_exact):
         gpu_ctx_exact.refit(2.0, 3.0)
 
 
+def test_tree_built_on_the_device(gpu_ctx, gpu_ctx_exact):
+    """pt_scene_build_device: the tree is rebuilt on the device (Morton sort, balanced tree, bottom-up fit) for a new
+    shutter window. Hits then agree with the oracle's on a scene whose BVH the host built for that window, and with
+    the hits through the host-built SAH tree; a refit afterwards works on the new tree."""
+    old, new = _moving_cloud(0.0, 1.0), _moving_cloud(2.0, 3.0)
+    rng = np.random.default_rng(23)
+    n = 60_000
+    rays = np.zeros(n, dtype=ptgpu.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-30, 130, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["time"] = rng.uniform(2.0, 3.0, size=n)
+    ref, _ = ob.intersect(new.desc(), rays)
+    gpu_ctx.upload(old)
+    gpu_ctx.build_tree_on_device(2.0, 3.0)
+    got = gpu_ctx.intersect(rays)
+    frac, max_rel, both = _compare_hits(got, ref)
+    assert both.mean() > 0.05
+    assert frac >= 0.9999 and max_rel <= 1e-7
+    gpu_ctx.upload(old)  # the host-built SAH tree, refitted to the same window: same primitives, same arithmetic
+    gpu_ctx.refit(2.0, 3.0)
+    sah = gpu_ctx.intersect(rays)
+    assert np.array_equal(sah["prim"], got["prim"]) and np.array_equal(sah["t"], got["t"], equal_nan=True)
+    # the device-built tree refits like the host-built one
+    gpu_ctx.upload(old)
+    gpu_ctx.build_tree_on_device(0.0, 1.0)
+    gpu_ctx.refit(2.0, 3.0)
+    again = gpu_ctx.intersect(rays)
+    assert np.array_equal(again["prim"], got["prim"]) and np.array_equal(again["t"], got["t"], equal_nan=True)
+    # wrapped, textured and volumetric primitives: the final scene through both trees
+    scene = ptgpu.Scene.named("final_book_two", 1.0)
+    primary = ob.camera_rays(scene.camera, 160, 160, np.arange(160 * 160, dtype=np.uint64), np.zeros(160 * 160, dtype=np.uint32))
+    gpu_ctx.upload(scene)
+    a = gpu_ctx.intersect(primary, medium_seed=5)
+    gpu_ctx.build_tree_on_device(0.0, 1.0)
+    b = gpu_ctx.intersect(primary, medium_seed=5)
+    assert (a["prim"] == b["prim"]).mean() >= 0.9999  # coplanar faces may tie either way
+    assert np.array_equal(a["t"], b["t"], equal_nan=True)
+    # a primitive-list scene has no tree; exact mode walks the reference's
+    gpu_ctx.upload(ptgpu.Scene.named("cornell_box", 1.0))
+    gpu_ctx.build_tree_on_device(0.0, 1.0)
+    gpu_ctx_exact.upload(old)
+    with pytest.raises(ptgpu.PtError):
+        gpu_ctx_exact.build_tree_on_device(2.0, 3.0)
+
+
 def test_converged_images_agree_across_independent_seeds():
     """The estimator, not the random stream: the device image at 4096 spp from one seed and the oracle image at
     512 spp from another are independent estimates of the same picture. After a 4x4 box filter their difference

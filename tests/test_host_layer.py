@@ -256,3 +256,4 @@ def test_accel_tree_invariants(name, param):
     assert 0 < info["n_prims"] <= flat["n_leaves"]  # medium boundaries own a leaf record but are not traversal ops
     assert 1 <= info["n_nodes"] < info["n_prims"]
     assert info["depth"] < 28
+
