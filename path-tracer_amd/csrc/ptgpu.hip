@@ -1062,15 +1062,18 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
 // throughput and RNG draw count.
 // FIRST: the vertex is the path's first one and nothing has initialised the path's accumulator: the vertex's
 // radiance (every branch adds at most once) is stored, zero included, instead of added.
-template <bool X, bool NEED_UV, bool FIRST = false>
+// RETURN: the vertex's radiance is handed back in `vertex_radiance` and nothing is written (the caller keeps the
+// path's sum).
+enum RadianceMode { RAD_ADD = 0, RAD_FIRST = 1, RAD_RETURN = 2 };
+template <bool X, bool NEED_UV, int FIRST = RAD_ADD>
 __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, D3 beta,
                                              uint64_t pkey, uint32_t pid, uint32_t &rn, double ht, int32_t id,
                                              uint32_t depth, uint32_t max_depth, uint32_t flags, double *lx, double *ly,
-                                             double *lz, D3 &no, D3 &nd, D3 &nbeta) {
+                                             double *lz, D3 &no, D3 &nd, D3 &nbeta, D3 *vertex_radiance = nullptr) {
     bool alive = false;
     D3 first = d3(0.0, 0.0, 0.0);
     auto add_radiance = [&](double *ax, double *ay, double *az, uint32_t path, D3 c) {
-        if constexpr (FIRST) first = c;
+        if constexpr (FIRST != RAD_ADD) first = c;
         else ::add_radiance(ax, ay, az, path, c);
     };
     if (id < 0) {
@@ -1205,11 +1208,12 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
         alive = !done && !dead;
         rn = g.n;
     }
-    if constexpr (FIRST) {
+    if constexpr (FIRST == RAD_FIRST) {
         lx[pid] = first.x;
         ly[pid] = first.y;
         lz[pid] = first.z;
     }
+    if constexpr (FIRST == RAD_RETURN) *vertex_radiance = first;
     return alive;
 }
 
@@ -1417,7 +1421,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_first_bounce(Queue q
         D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
         if (valid) {
             const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
-            alive = shade_vertex<false, NEED_UV, true>(sv, S.leaves[li].l, o, d, time, beta, g.key, pid, rn, ht, id, 0u,
+            alive = shade_vertex<false, NEED_UV, RAD_FIRST>(sv, S.leaves[li].l, o, d, time, beta, g.key, pid, rn, ht, id, 0u,
                                                        pp.max_depth, flags, lx, ly, lz, no, nd, nbeta);
         }
         const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], S.cnt);
@@ -1525,6 +1529,115 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_trace_persistent(Que
         qo = tmp;
         n = n_next;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Path pool form of the fused pipeline: ONE launch traces a whole offline pass and no path ever visits HBM. A wave is
+// a pool of 64 path slots over its own run of the pass's path ids: every round all 64 lanes walk the primitive list,
+// the lanes that hold a path shade their vertex and keep the next ray, throughput and radiance sum in registers; a
+// path that ends stores its radiance, and once enough slots are free the free lanes generate the next camera samples
+// of the run (ballot + prefix count; the run belongs to this wave alone). Queue entries, their compaction and the
+// launch per bounce are gone; what crosses HBM per PATH is the 24-B radiance the resolve kernel reads. Same camera
+// arithmetic and draws as k_raygen, same vertex code, same order of the per-path sum: images are bit-identical to
+// the other forms.
+// ------------------------------------------------------------------------------------------------------------
+struct PoolLds {
+    LdsLeaf leaves[kLdsLeaves];
+};
+template <bool NEED_UV, int FUSE>
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView sv, CameraDev cam, PassParams pp, double *lx,
+                                                                      double *ly, double *lz, uint32_t *counts,
+                                                                      uint32_t flags, uint32_t refill_at, uint32_t chunk) {
+    __shared__ PoolLds S;
+    {
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        __syncthreads(); // the only barrier of the kernel
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = pp.cpix * pp.s_count;
+    // Path ids are handed out in chunks from one counter (the first slot past the bounce rows of counts[], zero at
+    // launch and left out of the segment sum): a wave takes the next chunk when
+    // its current one is used up, so every wave stays full until the pass itself runs out of paths.
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    bool has = false;
+    D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), beta = d3(0.0, 0.0, 0.0), sum = d3(0.0, 0.0, 0.0);
+    double time = 0.0;
+    uint64_t pkey = 0;
+    uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle >= refill_at || n_idle == 64) {
+                if (cur >= end && !exhausted) {
+                    uint32_t first = 0;
+                    if (lane == 0) first = atomicAdd(&counts[(size_t)(pp.max_depth + 1) * kShards], chunk);
+                    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                    exhausted = first >= n;
+                    cur = min(first, n);
+                    end = min(cur + chunk, n); // chunk is far below 2^32 - n
+                }
+                if (cur < end) {
+                    const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (!has && cur + rank < end) {
+                        pid = cur + rank;
+                        const uint32_t p = pid % pp.cpix, s = pid / pp.cpix;
+                        const uint32_t i = pp.cx0 + p % pp.cw;
+                        const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+                        const uint64_t pixel = (uint64_t)jy * pp.width + i;
+                        Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
+                        double random = g.next(); // src/trace.rs:153-156
+                        const double u = ((double)i + random) / (double)pp.width;
+                        random = g.next();
+                        const double v = ((double)jy + random) / (double)pp.height;
+                        const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+                        const D3 offset = cam.u * rd.x + cam.v * rd.y;
+                        time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+                        d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+                        o = cam.origin + offset;
+                        beta = d3(1.0, 1.0, 1.0);
+                        pkey = g.key;
+                        rn = g.n;
+                        depth = 0;
+                        has = true;
+                    }
+                    cur += n_idle;
+                } else if (n_idle == 64) {
+                    break; // nothing in flight, nothing left to start
+                }
+            }
+        }
+        segments += (uint32_t)__popcll(__ballot(has));
+        double ht;
+        int32_t id;
+        extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along
+        if (has) {
+            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
+            D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
+            const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
+                                                                        id, depth, pp.max_depth, flags, lx, ly, lz, no, nd,
+                                                                        nbeta, &c);
+            // the per-path sum of the other forms: the first vertex is stored, later ones are added unless zero
+            if (depth == 0) sum = c;
+            else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+            if (alive) {
+                o = no;
+                d = nd;
+                beta = nbeta;
+                depth += 1;
+            } else {
+                lx[pid] = sum.x;
+                ly[pid] = sum.y;
+                lz[pid] = sum.z;
+                has = false;
+            }
+        }
+    }
+    if (lane == 0 && segments) atomicAdd(&counts[0], segments); // the pass's segment count, for the statistics
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1744,6 +1857,10 @@ struct pt_ctx {
     bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     uint32_t persist_factor = 1;
+    bool path_pool = true;        // offline fused passes as one k_path_pool launch
+    uint32_t pool_refill = 16;    // free path slots at which a wave generates new camera samples
+    uint32_t pool_grid = 1;       // workgroups per resident slot
+    uint32_t pool_chunk = 512;    // path ids a wave takes from the pass's counter at a time
     bool accel_pool = true;      // SAH traversal with lane refill (k_extend_accel_pool) instead of a ray per thread
     uint32_t accel_refill = 24;  // free lanes at which a wave takes new rays
     uint32_t accel_pool_from = 0; // first bounce traced by the pool form
@@ -1988,13 +2105,16 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // Measured on the Cornell box, one launch per pass against one per bounce: 2^20 paths +53 %, 2^22 +13 %,
     // 2^24 -3 %, 2^26 -7 % (the global compaction keeps every wave's tiles full and spreads the tail of long
     // paths over the whole chip); a 1080p realtime frame (0.4 M paths) +11 %.
-    const bool persistent = fused && ctx->persistent && n <= ctx->persistent_max_paths;
+    const bool pool = fused && ctx->path_pool && !realtime;
+    const bool persistent = fused && !pool && ctx->persistent && n <= ctx->persistent_max_paths;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
     // offline passes of fused scenes with a launch per bounce: bounce 0 generates its own rays
-    const bool gen0 = fused && !persistent && !realtime && ctx->fuse_first;
+    const bool gen0 = fused && !pool && !persistent && !realtime && ctx->fuse_first;
     HIP_TRY(ctx, mark());
-    if (gen0) {
+    if (pool) {
+        // no ray generation launch: the pool kernel makes its own camera samples
+    } else if (gen0) {
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_fused;
         v.n_traversal_ops = ctx->n_fused_ops;
@@ -2037,7 +2157,29 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         else launch(k_trace_persistent<false, 1>);
         HIP_TRY(ctx, mark());
     }
-    for (uint32_t d = persistent ? iters : 0; d < iters; ++d) {
+    if (pool) {
+        const uint32_t tiles = (n + 63u) / 64u;
+        const uint32_t resident = (uint32_t)ctx->n_cu * PT_SHADE_WAVES * ctx->pool_grid;
+        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
+        SceneView v = ctx->view;
+        v.ops = (const DevOp *)ctx->d_ops_fused;
+        v.n_traversal_ops = ctx->n_fused_ops;
+        HIP_TRY(ctx, mark());
+        HIP_TRY(ctx, mark());
+        HIP_TRY(ctx, mark());
+        const bool media = ctx->view.has_medium != 0;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, ctx->cam, pp, ctx->d_l[0], ctx->d_l[1],
+                               ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill, ctx->pool_chunk);
+        };
+        if (media && ctx->need_uv) launch(k_path_pool<true, 2>);
+        else if (media) launch(k_path_pool<false, 2>);
+        else if (ctx->need_uv) launch(k_path_pool<true, 1>);
+        else launch(k_path_pool<false, 1>);
+        HIP_TRY(ctx, mark());
+    }
+    const bool one_launch = persistent || pool;
+    for (uint32_t d = one_launch ? iters : 0; d < iters; ++d) {
         const Queue &qi = ctx->q[d & 1];
         const Queue &qo = ctx->q[(d + 1) & 1];
         const int g_d = grid_for_bounce(ctx, n, d);
@@ -2066,11 +2208,11 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
     ctx->stats.paths += n;
-    ctx->stats.launches_raygen += gen0 ? 0 : 1;
+    ctx->stats.launches_raygen += (gen0 || pool) ? 0 : 1;
     ctx->stats.launches_extend += fused ? 0 : iters;
-    ctx->stats.launches_shade += persistent ? 1 : (gen0 ? iters - 1 : iters);
+    ctx->stats.launches_shade += one_launch ? 1 : (gen0 ? iters - 1 : iters);
     ctx->stats.launches_resolve += 1;
-    if (profile || (read_counts && !persistent)) { // the one-launch form sizes no grids from the counts
+    if (profile || (read_counts && !one_launch)) { // the one-launch forms size no grids from the counts
         ctx->h_shard_counts.resize((size_t)(iters + 1) * kShards);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_shard_counts.data(), ctx->d_counts,
                                     ctx->h_shard_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2090,7 +2232,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         size_t k = 0;
         ctx->stats.ms_raygen += elapsed(k); // with gen0 this launch is k_first_bounce: ray generation AND bounce 0
         k += 2;
-        for (uint32_t d = 0; d < (persistent ? 1u : iters); ++d) {
+        for (uint32_t d = 0; d < (one_launch ? 1u : iters); ++d) {
             ctx->stats.ms_extend += elapsed(k);
             k += 2;
             ctx->stats.ms_shade += elapsed(k);
@@ -2101,7 +2243,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         ctx->stats.ms_resolve += elapsed(k);
         ctx->stats.profiled_paths += n;
         ctx->stats.profiled_passes += 1;
-        ctx->stats.profiled_bounce_launches += persistent ? 1 : (gen0 ? iters - 1 : iters);
+        ctx->stats.profiled_bounce_launches += one_launch ? 1 : (gen0 ? iters - 1 : iters);
     }
     return PT_OK;
 }
@@ -2139,6 +2281,10 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (const char *e = std::getenv("PTGPU_ACCEL_GRID")) ctx->accel_grid = (uint32_t)std::min(8l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_ACCEL_INNER")) ctx->accel_inner = (uint32_t)std::min(65l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_ACCEL_REFILL")) ctx->accel_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
+    if (const char *e = std::getenv("PTGPU_PATH_POOL")) ctx->path_pool = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("PTGPU_POOL_REFILL")) ctx->pool_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
+    if (const char *e = std::getenv("PTGPU_POOL_CHUNK")) ctx->pool_chunk = (uint32_t)std::min(1l << 20, std::max(64l, std::strtol(e, nullptr, 10)));
+    if (const char *e = std::getenv("PTGPU_POOL_GRID")) ctx->pool_grid = (uint32_t)std::min(256l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_PERSIST_FACTOR")) ctx->persist_factor = (uint32_t)std::max(1l, std::strtol(e, nullptr, 10));
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;

@@ -144,26 +144,44 @@ def test_realtime_1080p_frames():
 
 
 def test_pass_forms_give_the_same_image():
-    """The three ways a fused scene's pass is run -- one launch per pass with persistent waves (passes of at most 2^23
-    paths), a launch per bounce with a separate ray generation (realtime), and a launch per bounce whose bounce 0
-    generates its own rays (offline passes above 2^23 paths) -- trace the same paths: images are bit-identical."""
+    """The ways a fused scene's offline pass is run -- one launch whose waves keep a pool of paths in registers and
+    generate their own camera samples (the default), one launch per pass with persistent waves over queue tiles
+    (passes of at most 2^23 paths without the pool), and a launch per bounce whose bounce 0 generates its own rays
+    (larger passes without the pool) -- trace the same paths: images are bit-identical, whatever the pool's chunk
+    size and refill threshold."""
     scene = ptgpu.Scene.named("cornell_box", 1.0)
     w = h = 512
-    spp = 48  # 12.6 M paths: one pass above the threshold with a 2^24 budget, 13 passes below it with 2^20
-    big = ptgpu.Context(device=0, max_paths_in_flight=1 << 24)
-    big.upload(scene)
-    big.render(w, h, spp, 50)
-    a = big.readback()
-    st = big.stats()
-    big.close()
-    small = ptgpu.Context(device=0, max_paths_in_flight=1 << 20)
-    small.upload(scene)
-    small.render(w, h, spp, 50)
-    b = small.readback()
-    small.close()
+    spp = 48  # 12.6 M paths: one pass with a 2^24 budget, 13 passes with 2^20
+
+    def run(budget, env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            ctx = ptgpu.Context(device=0, max_paths_in_flight=budget)
+            ctx.upload(scene)
+            ctx.render(w, h, spp, 50)
+            img, st = ctx.readback(), ctx.stats()
+            ctx.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return img, st
+
+    a, st = run(1 << 24, {})
+    assert st.launches_raygen == 0 and st.launches_shade == st.launches_resolve == 1  # the pool: one launch per pass
+    assert np.isfinite(a[..., :3]).all() and a[..., :3].mean() > 0.05
+    b, st = run(1 << 24, {"PTGPU_PATH_POOL": "0"})
     assert st.launches_raygen == 0 and st.launches_shade > 1  # bounce 0 made its own rays, a launch per bounce
     assert np.array_equal(a, b, equal_nan=True)
-    assert np.isfinite(a[..., :3]).all() and a[..., :3].mean() > 0.05
+    segments = int(st.segments)
+    c, st = run(1 << 20, {"PTGPU_PATH_POOL": "0"})
+    assert st.launches_raygen == st.launches_shade == st.launches_resolve  # persistent waves: raygen + one launch
+    assert np.array_equal(a, c, equal_nan=True)
+    for env in ({"PTGPU_POOL_CHUNK": "64", "PTGPU_POOL_REFILL": "1"}, {"PTGPU_POOL_CHUNK": "100000", "PTGPU_POOL_REFILL": "64"},
+                {"PTGPU_POOL_GRID": "3", "PTGPU_POOL_REFILL": "40"}):
+        d, st = run(1 << 22, env)
+        assert np.array_equal(a, d, equal_nan=True), env
+        assert int(st.segments) == segments, env
 
 
 @pytest.mark.parametrize("name,param", [("sphere_cloud", 50000), ("final_book_two", 0)])
