@@ -202,6 +202,14 @@ def main():
         # bounce 0 of these passes runs in k_first_bounce (camera sample + walk + shade in one launch); the library
         # times it apart and leaves its segments out of profiled_segments, so the figures below are k_shade's alone
         gen0 = fused and int(st.launches_raygen) == 0
+        # one launch per pass and no ray generation launch: the path pool (k_path_pool), whose paths live in registers
+        # from camera sample to last vertex. It is priced like the fused kernel, at the queue entry in and out and the
+        # primitive + material record per segment that a wavefront formulation has to move; what it really moves is
+        # `traffic` (a radiance value per PATH), far below that.
+        pool = gen0 and int(st.launches_shade) == int(st.launches_resolve)
+        if pool:
+            gen0 = False
+            dominant = "path_pool"
         achieved = algorithmic / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
         # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
@@ -241,7 +249,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": {"extend": "k_extend_scan", "shade": "k_shade", "shade_fused": "k_shade<FUSE=1>"}[dominant],
+                "kernel": {"extend": "k_extend_accel_pool / k_extend_scan", "shade": "k_shade", "shade_fused": "k_shade<FUSE=1>",
+                           "path_pool": "k_path_pool<FUSE=1>"}[dominant],
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -257,6 +266,7 @@ def main():
                 "other": {
                     "fused_trace_shade": fused,
                     "bounce0_generates_rays": gen0,
+                    "path_pool": pool,
                     # the unfused two-kernel figure 204 + 32 (V + P), which prices every node / primitive visit as
                     # an HBM fetch, and the rate it would give; not used for `achieved`
                     "two_kernel_bytes_per_segment": b_ray + b_shade,

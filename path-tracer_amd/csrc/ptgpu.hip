@@ -1543,6 +1543,11 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_trace_persistent(Que
 // ------------------------------------------------------------------------------------------------------------
 struct PoolLds {
     LdsLeaf leaves[kLdsLeaves];
+    // camera samples made 64 at a time by the whole wave and handed to lanes as they fall free
+    double cam_ray[kWavesPerBlock][7][64]; // origin, direction, time
+    uint64_t cam_key[kWavesPerBlock][64];
+    uint32_t cam_rn[kWavesPerBlock][64];
+    uint32_t cam_pid[kWavesPerBlock][64];
 };
 template <bool NEED_UV, int FUSE>
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView sv, CameraDev cam, PassParams pp, double *lx,
@@ -1556,12 +1561,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
             ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
         __syncthreads(); // the only barrier of the kernel
     }
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t n = pp.cpix * pp.s_count;
     // Path ids are handed out in chunks from one counter (the first slot past the bounce rows of counts[], zero at
-    // launch and left out of the segment sum): a wave takes the next chunk when
-    // its current one is used up, so every wave stays full until the pass itself runs out of paths.
-    uint32_t cur = 0, end = 0;
+    // launch and left out of the segment sum): a wave takes the next chunk when its current one is used up, so every
+    // wave stays full until the pass itself runs out of paths.
+    uint32_t cur = 0, end = 0, stash_n = 0;
     bool exhausted = false;
     bool has = false;
     D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), beta = d3(0.0, 0.0, 0.0), sum = d3(0.0, 0.0, 0.0);
@@ -1569,10 +1574,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
     uint64_t pkey = 0;
     uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
     for (;;) {
-        const unsigned long long idle = __ballot(!has);
-        if (idle) {
+        bool drained = false;
+        for (;;) { // hand camera samples to free lanes
+            const unsigned long long idle = __ballot(!has);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= refill_at || n_idle == 64) {
+            if (n_idle < refill_at) break;
+            if (stash_n == 0) {
                 if (cur >= end && !exhausted) {
                     uint32_t first = 0;
                     if (lane == 0) first = atomicAdd(&counts[(size_t)(pp.max_depth + 1) * kShards], chunk);
@@ -1581,36 +1588,63 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
                     cur = min(first, n);
                     end = min(cur + chunk, n); // chunk is far below 2^32 - n
                 }
-                if (cur < end) {
-                    const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (!has && cur + rank < end) {
-                        pid = cur + rank;
-                        const uint32_t p = pid % pp.cpix, s = pid / pp.cpix;
-                        const uint32_t i = pp.cx0 + p % pp.cw;
-                        const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
-                        const uint64_t pixel = (uint64_t)jy * pp.width + i;
-                        Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
-                        double random = g.next(); // src/trace.rs:153-156
-                        const double u = ((double)i + random) / (double)pp.width;
-                        random = g.next();
-                        const double v = ((double)jy + random) / (double)pp.height;
-                        const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
-                        const D3 offset = cam.u * rd.x + cam.v * rd.y;
-                        time = cam.time0 + g.next() * (cam.time1 - cam.time0);
-                        d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
-                        o = cam.origin + offset;
-                        beta = d3(1.0, 1.0, 1.0);
-                        pkey = g.key;
-                        rn = g.n;
-                        depth = 0;
-                        has = true;
-                    }
-                    cur += n_idle;
-                } else if (n_idle == 64) {
-                    break; // nothing in flight, nothing left to start
+                if (cur >= end) { // the pass has no more paths to start
+                    drained = n_idle == 64;
+                    break;
                 }
+                // the next (up to) 64 camera samples, one per lane, parked in LDS
+                const uint32_t m = min(64u, end - cur);
+                const bool fresh = lane < m;
+                const uint32_t id = cur + lane;
+                uint32_t i = 0, jy = 0, smp = 0;
+                uint64_t pixel = 0;
+                if (fresh) {
+                    const uint32_t p = id % pp.cpix;
+                    smp = id / pp.cpix;
+                    i = pp.cx0 + p % pp.cw;
+                    jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+                    pixel = (uint64_t)jy * pp.width + i;
+                }
+                const unsigned long long made = __ballot(fresh);
+                if (fresh) {
+                    const uint32_t k = (uint32_t)__popcll(made & ((1ull << lane) - 1ull));
+                    Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + smp), 0};
+                    double random = g.next(); // src/trace.rs:153-156
+                    const double u = ((double)i + random) / (double)pp.width;
+                    random = g.next();
+                    const double v = ((double)jy + random) / (double)pp.height;
+                    const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+                    const D3 offset = cam.u * rd.x + cam.v * rd.y;
+                    const double t = cam.time0 + g.next() * (cam.time1 - cam.time0);
+                    const D3 dir = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+                    const D3 org = cam.origin + offset;
+                    S.cam_ray[wv][0][k] = org.x; S.cam_ray[wv][1][k] = org.y; S.cam_ray[wv][2][k] = org.z;
+                    S.cam_ray[wv][3][k] = dir.x; S.cam_ray[wv][4][k] = dir.y; S.cam_ray[wv][5][k] = dir.z;
+                    S.cam_ray[wv][6][k] = t;
+                    S.cam_key[wv][k] = g.key;
+                    S.cam_rn[wv][k] = g.n;
+                    S.cam_pid[wv][k] = id;
+                }
+                stash_n = (uint32_t)__popcll(made);
+                cur += m;
             }
+            const uint32_t take = min(n_idle, stash_n);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has && rank < take) {
+                const uint32_t k = stash_n - 1u - rank;
+                pid = S.cam_pid[wv][k];
+                o = d3(S.cam_ray[wv][0][k], S.cam_ray[wv][1][k], S.cam_ray[wv][2][k]);
+                d = d3(S.cam_ray[wv][3][k], S.cam_ray[wv][4][k], S.cam_ray[wv][5][k]);
+                time = S.cam_ray[wv][6][k];
+                pkey = S.cam_key[wv][k];
+                rn = S.cam_rn[wv][k];
+                beta = d3(1.0, 1.0, 1.0);
+                depth = 0;
+                has = true;
+            }
+            stash_n -= take;
         }
+        if (drained) break; // nothing in flight, nothing left to start
         segments += (uint32_t)__popcll(__ballot(has));
         double ht;
         int32_t id;
@@ -1858,7 +1892,7 @@ struct pt_ctx {
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     uint32_t persist_factor = 1;
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
-    uint32_t pool_refill = 16;    // free path slots at which a wave generates new camera samples
+    uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
     uint32_t pool_chunk = 512;    // path ids a wave takes from the pass's counter at a time
     bool accel_pool = true;      // SAH traversal with lane refill (k_extend_accel_pool) instead of a ray per thread
@@ -2105,6 +2139,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // Measured on the Cornell box, one launch per pass against one per bounce: 2^20 paths +53 %, 2^22 +13 %,
     // 2^24 -3 %, 2^26 -7 % (the global compaction keeps every wave's tiles full and spreads the tail of long
     // paths over the whole chip); a 1080p realtime frame (0.4 M paths) +11 %.
+    // (realtime frames, 0.4 M paths after the pixel skip, measured 16 % slower through the pool than through the
+    // persistent form below: four of five generated samples are skipped)
     const bool pool = fused && ctx->path_pool && !realtime;
     const bool persistent = fused && !pool && ctx->persistent && n <= ctx->persistent_max_paths;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
@@ -2161,6 +2197,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const uint32_t tiles = (n + 63u) / 64u;
         const uint32_t resident = (uint32_t)ctx->n_cu * PT_SHADE_WAVES * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
+        // a small pass is cut into at least four chunks per wave so that the waves finish together
+        const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
+        const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_fused;
         v.n_traversal_ops = ctx->n_fused_ops;
@@ -2170,7 +2209,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const bool media = ctx->view.has_medium != 0;
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, ctx->cam, pp, ctx->d_l[0], ctx->d_l[1],
-                               ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill, ctx->pool_chunk);
+                               ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill, chunk);
         };
         if (media && ctx->need_uv) launch(k_path_pool<true, 2>);
         else if (media) launch(k_path_pool<false, 2>);
