@@ -214,10 +214,12 @@ def main():
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
         # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
         traffic = None
+        pmc = {}
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof))[dominant]["hbm_bytes_per_unit"] * seg / n_launch
+                pmc = json.load(open(prof))[dominant]
+                traffic = pmc["hbm_bytes_per_unit"] * seg / n_launch
             except Exception:
                 traffic = None
         result = {
@@ -267,6 +269,9 @@ def main():
                     "fused_trace_shade": fused,
                     "bounce0_generates_rays": gen0,
                     "path_pool": pool,
+                    # from the committed PMC passes of this kernel: the pipe that actually bounds it
+                    "valu_busy_frac": pmc.get("valu_busy_frac"),
+                    "mean_active_lanes": pmc.get("mean_active_lanes"),
                     # the unfused two-kernel figure 204 + 32 (V + P), which prices every node / primitive visit as
                     # an HBM fetch, and the rate it would give; not used for `achieved`
                     "two_kernel_bytes_per_segment": b_ray + b_shade,
