@@ -206,10 +206,19 @@ def main():
         # from camera sample to last vertex. It is priced like the fused kernel, at the queue entry in and out and the
         # primitive + material record per segment that a wavefront formulation has to move; what it really moves is
         # `traffic` (a radiance value per PATH), far below that.
-        pool = gen0 and int(st.launches_shade) == int(st.launches_resolve)
+        form = int(st.last_pass_form)
+        pool = form == pt.PT_PASS_PATH_POOL
+        tree_pool = form == pt.PT_PASS_TREE_POOL
         if pool:
             gen0 = False
             dominant = "path_pool"
+        if tree_pool:
+            # tree scenes in one launch per pass: extend and shade of the same segment happen in the same lane, so
+            # the segment is priced at both stages' bytes minus the hit record and the ray re-read that no longer exist
+            gen0 = fused = False
+            dominant, dom_ms = "tree_pool", shd_ms
+            dom_bytes_unit = (b_ray - 36) + (b_shade - 8)
+            algorithmic = seg * dom_bytes_unit
         achieved = algorithmic / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE per segment, see
         # profiles/pmc_traffic.json) scaled to this run's units per launch; null if no PMC summary is committed.
@@ -252,7 +261,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": {"extend": "k_extend_accel_pool / k_extend_scan", "shade": "k_shade", "shade_fused": "k_shade<FUSE=1>",
-                           "path_pool": "k_path_pool<FUSE=1>"}[dominant],
+                           "path_pool": "k_path_pool<FUSE=1>", "tree_pool": "k_tree_pool"}[dominant],
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -269,6 +278,7 @@ def main():
                     "fused_trace_shade": fused,
                     "bounce0_generates_rays": gen0,
                     "path_pool": pool,
+                    "tree_pool": tree_pool,
                     # from the committed PMC passes of this kernel: the pipe that actually bounds it
                     "valu_busy_frac": pmc.get("valu_busy_frac"),
                     "mean_active_lanes": pmc.get("mean_active_lanes"),

@@ -227,7 +227,18 @@ typedef struct pt_stats {
     uint64_t profiled_paths;   /* paths processed by the profiled raygen/resolve launches */
     uint64_t profiled_passes;  /* profiled raygen (= resolve) launches */
     uint64_t profiled_bounce_launches; /* profiled extend (= shade) launches */
+    uint64_t last_pass_form;   /* pt_pass_form of the most recent pass */
 } pt_stats;
+
+/* How the library ran a pass (it chooses; none of them changes a pixel). */
+enum pt_pass_form {
+    PT_PASS_NONE = 0,
+    PT_PASS_PER_BOUNCE = 1,       /* ray generation, then an extend and a shade launch per bounce */
+    PT_PASS_PER_BOUNCE_FUSED = 2, /* primitive-list scenes: one trace+shade launch per bounce */
+    PT_PASS_PERSISTENT = 3,       /* primitive-list scenes: ray generation + one launch over queue tiles */
+    PT_PASS_PATH_POOL = 4,        /* primitive-list scenes, offline: one launch, paths stay in registers */
+    PT_PASS_TREE_POOL = 5         /* tree scenes, offline: one launch, traversal and shading inside the wave */
+};
 
 /* No reference counterpart (the crate owns no device); allocates the per-GPU state. */
 int pt_create(const pt_config *cfg, pt_ctx **out);

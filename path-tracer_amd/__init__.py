@@ -182,6 +182,9 @@ class RenderArgs(C.Structure):
     ]
 
 
+PT_PASS_NONE, PT_PASS_PER_BOUNCE, PT_PASS_PER_BOUNCE_FUSED, PT_PASS_PERSISTENT, PT_PASS_PATH_POOL, PT_PASS_TREE_POOL = range(6)
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("paths", C.c_uint64),
@@ -201,6 +204,7 @@ class Stats(C.Structure):
         ("profiled_paths", C.c_uint64),
         ("profiled_passes", C.c_uint64),
         ("profiled_bounce_launches", C.c_uint64),
+        ("last_pass_form", C.c_uint64),
     ]
 
 

@@ -1675,6 +1675,158 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The path pool for scenes that are traced through the SAH tree: one launch per offline pass, a path in one lane's
+// registers from camera sample to last vertex, no queues. A lane is free, on an inner node, on a leaf, or waiting
+// with a finished traversal. Every round steps the traversing lanes (inner nodes first, then leaves, as in
+// k_extend_accel_pool), and once enough lanes wait (or too few still traverse) the waiting lanes shade their vertex
+// together and start their next ray; free lanes take new camera samples from the pass's chunk counter.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef PT_TREE_UV_WAVES
+#define PT_TREE_UV_WAVES 2 // waves per SIMD of the textured variants: their shading is the largest code here (4: 638, 3: 640, 2: 730 Mpaths/s on the final scene)
+#endif
+template <bool NEED_UV, bool MEDIA>
+__global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
+                                                                      CameraDev cam, PassParams pp, double *lx, double *ly,
+                                                                      double *lz, uint32_t *counts, uint32_t flags,
+                                                                      uint32_t tuning, uint32_t chunk) {
+    __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
+    const uint32_t refill_at = tuning & 0xffu, inner_min = (tuning >> 8) & 0xffu, shade_min = (tuning >> 16) & 0xffu,
+                   trav_min = tuning >> 24;
+    constexpr int32_t kDone = INT32_MIN; // never a leaf reference
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = pp.cpix * pp.s_count;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    bool has = false;
+    D3 o = d3(0, 0, 0), d = d3(0, 0, 1), inv = o, beta = o, sum = o;
+    double time = 0.0, closest = 0.0;
+    uint64_t pkey = 0;
+    uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
+    int32_t best = -1, node = kDone;
+    int sp = 0;
+    auto start_ray = [&]() { // (o, d) hold a new ray
+        inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+        closest = kF64Max;
+        best = -1;
+        sp = 0;
+        // rays with a NaN or infinite component are not traced (see k_extend_accel)
+        const double probe = (o.x + o.y + o.z) + (d.x + d.y + d.z);
+        node = (probe == probe && fabs(probe) <= kF64Max) ? 0 : kDone;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle >= refill_at) {
+            if (cur >= end && !exhausted) {
+                uint32_t first = 0;
+                if (lane == 0) first = atomicAdd(&counts[(size_t)(pp.max_depth + 1) * kShards], chunk);
+                first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                exhausted = first >= n;
+                cur = min(first, n);
+                end = min(cur + chunk, n);
+            }
+            if (cur < end) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!has && cur + rank < end) {
+                    pid = cur + rank;
+                    const uint32_t p = pid % pp.cpix, s = pid / pp.cpix;
+                    const uint32_t i = pp.cx0 + p % pp.cw;
+                    const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+                    const uint64_t pixel = (uint64_t)jy * pp.width + i;
+                    Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
+                    double random = g.next(); // src/trace.rs:153-156
+                    const double u = ((double)i + random) / (double)pp.width;
+                    random = g.next();
+                    const double v = ((double)jy + random) / (double)pp.height;
+                    const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+                    const D3 offset = cam.u * rd.x + cam.v * rd.y;
+                    time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+                    d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+                    o = cam.origin + offset;
+                    beta = d3(1.0, 1.0, 1.0);
+                    pkey = g.key;
+                    rn = g.n;
+                    depth = 0;
+                    has = true;
+                    start_ray();
+                }
+                cur = min(cur + n_idle, end);
+            } else if (n_idle == 64) {
+                break; // nothing in flight, nothing left to start
+            }
+        }
+        // traversal: inner nodes for as long as at least `inner_min` lanes are on one, then the leaves
+        for (;;) {
+            if (has && node >= 0) {
+                const AccelNode &nd = nodes[node];
+                double t0, t1;
+                const bool h0 = accel_box(nd.lo[0], nd.hi[0], o, inv, 0.001, closest, t0);
+                const bool h1 = accel_box(nd.lo[1], nd.hi[1], o, inv, 0.001, closest, t1);
+                const int32_t c0 = nd.child[0], c1 = nd.child[1];
+                if (h0 && h1) {
+                    const bool first0 = t0 <= t1;
+                    stack[sp++][threadIdx.x] = first0 ? c1 : c0;
+                    node = first0 ? c0 : c1;
+                } else if (h0 || h1) {
+                    node = h0 ? c0 : c1;
+                } else {
+                    node = sp ? stack[--sp][threadIdx.x] : kDone;
+                }
+            }
+            const uint32_t n_inner = (uint32_t)__popcll(__ballot(has && node >= 0));
+            if (n_inner == 0 || n_inner < inner_min) break;
+        }
+        if (has && node < 0 && node != kDone) {
+            const int32_t ref = ~node;
+            const int32_t first = ref >> 3, count = ref & 7;
+            for (int32_t k = first; k < first + count; ++k) {
+                const DevOp op = prims[k];
+                double t = 0.0;
+                int sub = 0;
+                bool hit;
+                if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
+                    hit = medium_hit<false>(sv, op, o, d, inv, time, 0.001, closest, pkey, depth, t);
+                else hit = prim_hit<false>(sv, op, o, d, inv, time, 0.001, closest, t, sub);
+                if (hit) {
+                    closest = t;
+                    best = op.leaf | (sub << 28);
+                }
+            }
+            node = sp ? stack[--sp][threadIdx.x] : kDone;
+        }
+        // vertices: when enough lanes wait with a finished traversal, or too few are still traversing to go on
+        const bool ready = has && node == kDone;
+        const uint32_t n_ready = (uint32_t)__popcll(__ballot(ready));
+        const uint32_t n_trav = (uint32_t)__popcll(__ballot(has && node != kDone));
+        if (n_ready && (n_ready >= shade_min || n_trav <= trav_min)) {
+            segments += n_ready;
+            if (ready) {
+                const int32_t li = best < 0 ? 0 : (best & 0x0fffffff);
+                D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
+                const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
+                                                                            closest, best, depth, pp.max_depth, flags, lx, ly,
+                                                                            lz, no, nd, nbeta, &c);
+                if (depth == 0) sum = c; // the per-path sum of the other forms
+                else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+                if (alive) {
+                    o = no;
+                    d = nd;
+                    beta = nbeta;
+                    depth += 1;
+                    start_ray();
+                } else {
+                    lx[pid] = sum.x;
+                    ly[pid] = sum.y;
+                    lz[pid] = sum.z;
+                    has = false;
+                }
+            }
+        }
+    }
+    if (lane == 0 && segments) atomicAdd(&counts[0], segments);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // resolve: per-pixel sum in sample order, then the write of src/trace.rs:166-182
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const double *ly, const double *lz, double *ax,
@@ -1891,6 +2043,8 @@ struct pt_ctx {
     bool fuse_ok = false;          // the scene has a fused-kernel op list (d_ops_fused)
     uint32_t render_flags = 0;     // pt_render_args.flags of the render call in progress
     uint32_t persist_factor = 1;
+    bool tree_pool = true;        // offline passes of tree scenes as one k_tree_pool launch
+    uint32_t tree_tuning[4] = {16, 16, 32, 4}; // refill at / inner min / shade min / traversing min
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
@@ -2142,14 +2296,15 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // (realtime frames, 0.4 M paths after the pixel skip, measured 16 % slower through the pool than through the
     // persistent form below: four of five generated samples are skipped)
     const bool pool = fused && ctx->path_pool && !realtime;
+    const bool tree = !fused && !realtime && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count;
     const bool persistent = fused && !pool && ctx->persistent && n <= ctx->persistent_max_paths;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
     // offline passes of fused scenes with a launch per bounce: bounce 0 generates its own rays
     const bool gen0 = fused && !pool && !persistent && !realtime && ctx->fuse_first;
     HIP_TRY(ctx, mark());
-    if (pool) {
-        // no ray generation launch: the pool kernel makes its own camera samples
+    if (pool || tree) {
+        // no ray generation launch: the pool kernels make their own camera samples
     } else if (gen0) {
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_fused;
@@ -2217,7 +2372,29 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         else launch(k_path_pool<false, 1>);
         HIP_TRY(ctx, mark());
     }
-    const bool one_launch = persistent || pool;
+    if (tree) {
+        const uint32_t tiles = (n + 63u) / 64u;
+        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->need_uv ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
+        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
+        const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
+        const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        const uint32_t tuning = ctx->tree_tuning[0] | (ctx->tree_tuning[1] << 8) | (ctx->tree_tuning[2] << 16) | (ctx->tree_tuning[3] << 24);
+        HIP_TRY(ctx, mark());
+        HIP_TRY(ctx, mark());
+        HIP_TRY(ctx, mark());
+        const bool media = ctx->view.has_medium != 0;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
+                               (const DevOp *)ctx->d_accel_prims, ctx->cam, pp, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2],
+                               ctx->d_counts, ctx->render_flags, tuning, chunk);
+        };
+        if (media && ctx->need_uv) launch(k_tree_pool<true, true>);
+        else if (media) launch(k_tree_pool<false, true>);
+        else if (ctx->need_uv) launch(k_tree_pool<true, false>);
+        else launch(k_tree_pool<false, false>);
+        HIP_TRY(ctx, mark());
+    }
+    const bool one_launch = persistent || pool || tree;
     for (uint32_t d = one_launch ? iters : 0; d < iters; ++d) {
         const Queue &qi = ctx->q[d & 1];
         const Queue &qo = ctx->q[(d + 1) & 1];
@@ -2247,10 +2424,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
     ctx->stats.paths += n;
-    ctx->stats.launches_raygen += (gen0 || pool) ? 0 : 1;
-    ctx->stats.launches_extend += fused ? 0 : iters;
+    ctx->stats.launches_raygen += (gen0 || pool || tree) ? 0 : 1;
+    ctx->stats.launches_extend += (fused || tree) ? 0 : iters;
     ctx->stats.launches_shade += one_launch ? 1 : (gen0 ? iters - 1 : iters);
     ctx->stats.launches_resolve += 1;
+    ctx->stats.last_pass_form = tree ? PT_PASS_TREE_POOL : pool ? PT_PASS_PATH_POOL : persistent ? PT_PASS_PERSISTENT
+                                : fused ? PT_PASS_PER_BOUNCE_FUSED : PT_PASS_PER_BOUNCE;
     if (profile || (read_counts && !one_launch)) { // the one-launch forms size no grids from the counts
         ctx->h_shard_counts.resize((size_t)(iters + 1) * kShards);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_shard_counts.data(), ctx->d_counts,
@@ -2320,6 +2499,12 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (const char *e = std::getenv("PTGPU_ACCEL_GRID")) ctx->accel_grid = (uint32_t)std::min(8l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_ACCEL_INNER")) ctx->accel_inner = (uint32_t)std::min(65l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_ACCEL_REFILL")) ctx->accel_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
+    if (const char *e = std::getenv("PTGPU_TREE_POOL")) ctx->tree_pool = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("PTGPU_TREE_TUNING")) { // "refill,inner,shade,trav"
+        unsigned v[4];
+        if (std::sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int k = 0; k < 4; ++k) ctx->tree_tuning[k] = std::min(255u, std::max(k == 3 ? 0u : 1u, v[k]));
+    }
     if (const char *e = std::getenv("PTGPU_PATH_POOL")) ctx->path_pool = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_POOL_REFILL")) ctx->pool_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_POOL_CHUNK")) ctx->pool_chunk = (uint32_t)std::min(1l << 20, std::max(64l, std::strtol(e, nullptr, 10)));

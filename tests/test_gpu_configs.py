@@ -214,3 +214,35 @@ def test_tree_traversal_forms_agree(name, param):
             assert np.array_equal(a["prim"], b["prim"]), env
             assert np.array_equal(a["t"], b["t"], equal_nan=True), env
     assert (base[0]["prim"] >= 0).mean() > 0.1
+
+
+@pytest.mark.parametrize("name,param", [("random_scene", 0), ("final_book_two", 0), ("sphere_cloud", 50000)])
+def test_tree_pool_gives_the_same_image(name, param):
+    """Scenes traced through the SAH tree: an offline pass run as one launch whose lanes carry a path each (traversal
+    and shading interleaved inside the wave) against ray generation plus an extend and a shade launch per bounce.
+    Same paths, same arithmetic per path: bit-identical images and segment counts, whatever the thresholds."""
+    scene = ptgpu.Scene.named(name, 4 / 3, param=param)
+    w, h, spp = 160, 120, 6
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            ctx = _ctx(max_paths_in_flight=1 << 16)
+            ctx.upload(scene)
+            ctx.render(w, h, spp, 50)
+            img, st = ctx.readback(), ctx.stats()
+            ctx.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return img, st
+
+    a, st_a = run({"PTGPU_TREE_POOL": "0"})
+    assert st_a.launches_extend > 0
+    for env in ({"PTGPU_TREE_POOL": "1"}, {"PTGPU_TREE_POOL": "1", "PTGPU_TREE_TUNING": "1,1,1,0"},
+                {"PTGPU_TREE_POOL": "1", "PTGPU_TREE_TUNING": "64,64,64,63", "PTGPU_POOL_CHUNK": "64"}):
+        b, st_b = run(env)
+        assert st_b.launches_extend == 0 and st_b.launches_raygen == 0, env
+        assert np.array_equal(a, b, equal_nan=True), env
+        assert int(st_a.segments) == int(st_b.segments), env
