@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -1541,6 +1542,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_trace_persistent(Que
 // arithmetic and draws as k_raygen, same vertex code, same order of the per-path sum: images are bit-identical to
 // the other forms.
 // ------------------------------------------------------------------------------------------------------------
+// Camera and pass constants of the pool kernel, read from memory where camera samples are made: as kernel arguments
+// they would sit in some sixty scalar registers for the whole kernel, which the walk and the shading need themselves.
+struct PoolConsts {
+    CameraDev cam;
+    PassParams pp;
+};
 struct PoolLds {
     LdsLeaf leaves[kLdsLeaves];
     // camera samples made 64 at a time by the whole wave and handed to lanes as they fall free
@@ -1550,9 +1557,10 @@ struct PoolLds {
     uint32_t cam_pid[kWavesPerBlock][64];
 };
 template <bool NEED_UV, int FUSE>
-__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView sv, CameraDev cam, PassParams pp, double *lx,
-                                                                      double *ly, double *lz, uint32_t *counts,
-                                                                      uint32_t flags, uint32_t refill_at, uint32_t chunk) {
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
+                                                                      uint32_t max_depth, double *lx, double *ly,
+                                                                      double *lz, uint32_t *counts, uint32_t flags,
+                                                                      uint32_t refill_at, uint32_t chunk) {
     __shared__ PoolLds S;
     {
         constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
@@ -1562,7 +1570,6 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
         __syncthreads(); // the only barrier of the kernel
     }
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t n = pp.cpix * pp.s_count;
     // Path ids are handed out in chunks from one counter (the first slot past the bounce rows of counts[], zero at
     // launch and left out of the segment sum): a wave takes the next chunk when its current one is used up, so every
     // wave stays full until the pass itself runs out of paths.
@@ -1582,7 +1589,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
             if (stash_n == 0) {
                 if (cur >= end && !exhausted) {
                     uint32_t first = 0;
-                    if (lane == 0) first = atomicAdd(&counts[(size_t)(pp.max_depth + 1) * kShards], chunk);
+                    if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
                     first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
                     exhausted = first >= n;
                     cur = min(first, n);
@@ -1593,6 +1600,10 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
                     break;
                 }
                 // the next (up to) 64 camera samples, one per lane, parked in LDS
+                const PoolConsts *pc = consts;
+                asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+                const CameraDev cam = pc->cam;
+                const PassParams pp = pc->pp;
                 const uint32_t m = min(64u, end - cur);
                 const bool fresh = lane < m;
                 const uint32_t id = cur + lane;
@@ -1653,7 +1664,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
             const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
             D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
             const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
-                                                                        id, depth, pp.max_depth, flags, lx, ly, lz, no, nd,
+                                                                        id, depth, max_depth, flags, lx, ly, lz, no, nd,
                                                                         nbeta, &c);
             // the per-path sum of the other forms: the first vertex is stored, later ones are added unless zero
             if (depth == 0) sum = c;
@@ -2045,6 +2056,8 @@ struct pt_ctx {
     uint32_t persist_factor = 1;
     bool tree_pool = true;        // offline passes of tree scenes as one k_tree_pool launch
     uint32_t tree_tuning[4] = {16, 16, 32, 4}; // refill at / inner min / shade min / traversing min
+    void *d_pool_consts = nullptr;
+    std::deque<PoolConsts> h_pool_consts; // host copies of the passes in flight (cleared at every stream synchronisation of a render)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
@@ -2362,9 +2375,13 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
         const bool media = ctx->view.has_medium != 0;
+        if (!ctx->d_pool_consts) HIP_TRY(ctx, hipMalloc(&ctx->d_pool_consts, sizeof(PoolConsts)));
+        ctx->h_pool_consts.emplace_back(PoolConsts{ctx->cam, pp}); // must outlive the asynchronous copy
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pool_consts, &ctx->h_pool_consts.back(), sizeof(PoolConsts), hipMemcpyHostToDevice, st));
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, ctx->cam, pp, ctx->d_l[0], ctx->d_l[1],
-                               ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill, chunk);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, (const PoolConsts *)ctx->d_pool_consts, n,
+                               pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
+                               ctx->pool_refill, chunk);
         };
         if (media && ctx->need_uv) launch(k_path_pool<true, 2>);
         else if (media) launch(k_path_pool<false, 2>);
@@ -2538,7 +2555,7 @@ void pt_destroy(pt_ctx *ctx) {
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
-                    ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2]};
+                    ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto e : ctx->events) (void)hipEventDestroy(e);
@@ -2797,6 +2814,7 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->h_pool_consts.clear();
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }
