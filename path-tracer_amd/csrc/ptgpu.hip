@@ -1697,15 +1697,14 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
 #endif
 template <bool NEED_UV, bool MEDIA>
 __global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
-                                                                      CameraDev cam, PassParams pp, double *lx, double *ly,
-                                                                      double *lz, uint32_t *counts, uint32_t flags,
-                                                                      uint32_t tuning, uint32_t chunk) {
+                                                                      const PoolConsts *consts, uint32_t n, uint32_t max_depth,
+                                                                      double *lx, double *ly, double *lz, uint32_t *counts,
+                                                                      uint32_t flags, uint32_t tuning, uint32_t chunk) {
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
     const uint32_t refill_at = tuning & 0xffu, inner_min = (tuning >> 8) & 0xffu, shade_min = (tuning >> 16) & 0xffu,
                    trav_min = tuning >> 24;
     constexpr int32_t kDone = INT32_MIN; // never a leaf reference
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n = pp.cpix * pp.s_count;
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
     bool has = false;
@@ -1730,7 +1729,7 @@ __global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES
         if (n_idle >= refill_at) {
             if (cur >= end && !exhausted) {
                 uint32_t first = 0;
-                if (lane == 0) first = atomicAdd(&counts[(size_t)(pp.max_depth + 1) * kShards], chunk);
+                if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
                 first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
                 exhausted = first >= n;
                 cur = min(first, n);
@@ -1739,6 +1738,10 @@ __global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES
             if (cur < end) {
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (!has && cur + rank < end) {
+                    const PoolConsts *pc = consts;
+                    asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+                    const CameraDev cam = pc->cam;
+                    const PassParams pp = pc->pp;
                     pid = cur + rank;
                     const uint32_t p = pid % pp.cpix, s = pid / pp.cpix;
                     const uint32_t i = pp.cx0 + p % pp.cw;
@@ -1815,7 +1818,7 @@ __global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES
                 const int32_t li = best < 0 ? 0 : (best & 0x0fffffff);
                 D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
                 const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
-                                                                            closest, best, depth, pp.max_depth, flags, lx, ly,
+                                                                            closest, best, depth, max_depth, flags, lx, ly,
                                                                             lz, no, nd, nbeta, &c);
                 if (depth == 0) sum = c; // the per-path sum of the other forms
                 else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
@@ -2316,6 +2319,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // offline passes of fused scenes with a launch per bounce: bounce 0 generates its own rays
     const bool gen0 = fused && !pool && !persistent && !realtime && ctx->fuse_first;
     HIP_TRY(ctx, mark());
+    auto send_pool_consts = [&]() -> hipError_t {
+        if (!ctx->d_pool_consts)
+            if (hipError_t e = hipMalloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
+        ctx->h_pool_consts.emplace_back(PoolConsts{ctx->cam, pp}); // must outlive the asynchronous copy
+        return hipMemcpyAsync(ctx->d_pool_consts, &ctx->h_pool_consts.back(), sizeof(PoolConsts), hipMemcpyHostToDevice, st);
+    };
     if (pool || tree) {
         // no ray generation launch: the pool kernels make their own camera samples
     } else if (gen0) {
@@ -2375,9 +2384,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
         const bool media = ctx->view.has_medium != 0;
-        if (!ctx->d_pool_consts) HIP_TRY(ctx, hipMalloc(&ctx->d_pool_consts, sizeof(PoolConsts)));
-        ctx->h_pool_consts.emplace_back(PoolConsts{ctx->cam, pp}); // must outlive the asynchronous copy
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pool_consts, &ctx->h_pool_consts.back(), sizeof(PoolConsts), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, send_pool_consts());
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, (const PoolConsts *)ctx->d_pool_consts, n,
                                pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
@@ -2395,6 +2402,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
         const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        HIP_TRY(ctx, send_pool_consts());
         const uint32_t tuning = ctx->tree_tuning[0] | (ctx->tree_tuning[1] << 8) | (ctx->tree_tuning[2] << 16) | (ctx->tree_tuning[3] << 24);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
@@ -2402,8 +2410,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const bool media = ctx->view.has_medium != 0;
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
-                               (const DevOp *)ctx->d_accel_prims, ctx->cam, pp, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2],
-                               ctx->d_counts, ctx->render_flags, tuning, chunk);
+                               (const DevOp *)ctx->d_accel_prims, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
+                               ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
         };
         if (media && ctx->need_uv) launch(k_tree_pool<true, true>);
         else if (media) launch(k_tree_pool<false, true>);
