@@ -351,13 +351,79 @@ __device__ __forceinline__ bool aabb_hit_fast(const double *b, D3 o, D3 inv, dou
     return ok && (tmax > tmin);
 }
 
+// The wave walks the threaded op stream together: op records come through the scalar cache into SGPRs and each lane
+// is predicated on "my next op", so results are those of the per-lane walk. (wo, wd) is the world ray; `valid` lanes
+// take part. Must be called by all 64 lanes of a wave.
 // LIST: the stream holds no BOX ops (see pt_scene_upload), so every lane wants every op and no per-lane index
 // is kept at all.
+template <bool X, bool FRAMES, bool MEDIA, bool LIST>
+__device__ __forceinline__ void extend_scan_walk(const SceneView &sv, D3 wo, D3 wd, double time, uint64_t pkey,
+                                                 uint32_t depth, double t_min, double t_max, bool valid, bool count,
+                                                 double &closest, int32_t &best, unsigned long long &my_nodes,
+                                                 unsigned long long &my_prims) {
+    const int32_t end = sv.n_traversal_ops;
+    D3 o = wo, d = wd;
+    D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+    closest = t_max;
+    best = -1;
+    int32_t cur = valid ? 0 : 0x7fffffff;
+    int32_t c = -1;
+    for (;;) {
+        c += 1;
+        if (!LIST) {
+            if (__ballot(cur == c) == 0ull) c = wave_min_i32(cur); // nobody wants the next op: jump ahead
+            c = __builtin_amdgcn_readfirstlane(c);
+        }
+        if (c >= end) break;
+        const DevOp op = load_op_uniform(sv.ops + c); // uniform address: scalar loads into SGPRs
+        const int32_t kword = __builtin_amdgcn_readfirstlane(op.kind);
+        const int kind = kword & 0xff;
+        const bool mine = LIST ? valid : (cur == c);
+        if (!LIST && kind == OP_BOX) {
+            if (count && mine) ++my_nodes;
+            bool hit;
+            if constexpr (X) hit = aabb_hit(op.d, o, inv, t_min, closest);
+            else hit = aabb_hit_fast(op.d, o, inv, t_min, closest);
+            cur = mine ? (hit ? c + 1 : op.skip) : cur;
+        } else if (FRAMES && (kind == OP_ENTER || kind == OP_EXIT)) {
+            D3 no, nd;
+            if (kind == OP_ENTER) {
+                no = o;
+                nd = d;
+            } else { // back to the enclosing frame: world ray, then that frame's chain
+                no = wo;
+                nd = wd;
+            }
+            apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, no, nd);
+            if (mine) {
+                o = no;
+                d = nd;
+                inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
+                cur = c + 1;
+            }
+        } else {
+            double t = 0.0;
+            int sub = 0;
+            bool hit;
+            if (MEDIA && kind == OP_MEDIUM) {
+                if (count && mine) my_prims += 2;
+                hit = medium_hit<X>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
+            } else {
+                if (count && mine) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
+                hit = prim_hit<X>(sv, op, o, d, inv, time, t_min, closest, t, sub);
+            }
+            const bool take = mine && hit;
+            closest = take ? t : closest;
+            best = take ? (op.leaf | (sub << 28)) : best;
+            cur = mine ? c + 1 : cur;
+        }
+    }
+}
+
 template <bool X, bool FRAMES, bool MEDIA, bool LIST>
 __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, ExtendArgs a) {
     const bool count = a.counters != nullptr;
     unsigned long long my_nodes = 0, my_prims = 0;
-    const int32_t end = sv.n_traversal_ops;
     const uint32_t n_virtual = ((max_shard_count(a.counts, a.sh.shards) + kBlock - 1) / kBlock) << a.sh.shift;
     for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
         const uint32_t s_id = v & (a.sh.shards - 1);
@@ -368,66 +434,15 @@ __global__ __launch_bounds__(kBlock) void k_extend_scan(Queue q, SceneView sv, E
         const bool valid = local < ns;
         const uint32_t i = s_id * a.sh.shard_cap + local;
         const uint32_t il = valid ? i : s_id * a.sh.shard_cap;
-        D3 o = d3(q.ox(il), q.oy(il), q.oz(il));
-        D3 d = d3(q.dx(il), q.dy(il), q.dz(il));
+        const D3 o = d3(q.ox(il), q.oy(il), q.oz(il));
+        const D3 d = d3(q.dx(il), q.dy(il), q.dz(il));
         const double time = q.tm(il);
         uint64_t pkey = 0;
         if (MEDIA) pkey = (a.key_mode == 0) ? q.key(il) : intersect_key(a.medium_seed, il);
-        D3 inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-        double closest = a.t_max;
-        int32_t best = -1;
-        int32_t cur = valid ? 0 : 0x7fffffff;
-        int32_t c = -1;
-        for (;;) {
-            c += 1;
-            if (!LIST) {
-                if (__ballot(cur == c) == 0ull) c = wave_min_i32(cur); // nobody wants the next op: jump ahead
-                c = __builtin_amdgcn_readfirstlane(c);
-            }
-            if (c >= end) break;
-            const DevOp op = load_op_uniform(sv.ops + c); // uniform address: scalar loads into SGPRs
-            const int32_t kword = __builtin_amdgcn_readfirstlane(op.kind);
-            const int kind = kword & 0xff;
-            const bool mine = LIST ? valid : (cur == c);
-            if (!LIST && kind == OP_BOX) {
-                if (count && mine) ++my_nodes;
-                bool hit;
-                if constexpr (X) hit = aabb_hit(op.d, o, inv, a.t_min, closest);
-                else hit = aabb_hit_fast(op.d, o, inv, a.t_min, closest);
-                cur = mine ? (hit ? c + 1 : op.skip) : cur;
-            } else if (FRAMES && (kind == OP_ENTER || kind == OP_EXIT)) {
-                D3 no, nd;
-                if (kind == OP_ENTER) {
-                    no = o;
-                    nd = d;
-                } else { // back to the enclosing frame: world ray, then that frame's chain
-                    no = d3(q.ox(il), q.oy(il), q.oz(il));
-                    nd = d3(q.dx(il), q.dy(il), q.dz(il));
-                }
-                apply_chain<X>(sv.xforms, op.chain_start, (kword >> 16) & 0xff, no, nd);
-                if (mine) {
-                    o = no;
-                    d = nd;
-                    inv = d3(M<X>::rcp(d.x), M<X>::rcp(d.y), M<X>::rcp(d.z));
-                    cur = c + 1;
-                }
-            } else {
-                double t = 0.0;
-                int sub = 0;
-                bool hit;
-                if (MEDIA && kind == OP_MEDIUM) {
-                    if (count && mine) my_prims += 2;
-                    hit = medium_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t);
-                } else {
-                    if (count && mine) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
-                    hit = prim_hit<X>(sv, op, o, d, inv, time, a.t_min, closest, t, sub);
-                }
-                const bool take = mine && hit;
-                closest = take ? t : closest;
-                best = take ? (op.leaf | (sub << 28)) : best;
-                cur = mine ? c + 1 : cur;
-            }
-        }
+        double closest;
+        int32_t best;
+        extend_scan_walk<X, FRAMES, MEDIA, LIST>(sv, o, d, time, pkey, a.depth, a.t_min, a.t_max, valid, count, closest, best,
+                                                 my_nodes, my_prims);
         if (valid) {
             a.hit_t[i] = closest;
             a.hit_id[i] = best;
@@ -1556,8 +1571,13 @@ struct PoolLds {
     uint32_t cam_rn[kWavesPerBlock][64];
     uint32_t cam_pid[kWavesPerBlock][64];
 };
-template <bool NEED_UV, int FUSE>
-__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
+#ifndef PT_EXACT_POOL_WAVES
+#define PT_EXACT_POOL_WAVES 3 // measured on the Cornell box: 1 -> 895, 2 -> 1506, 3 -> 1786, 4 -> 1704 Mpaths/s
+#endif
+// X: exact mode. The walk is the wave-uniform scan of the reference's own threaded tree (every box test, the
+// reference's order), the arithmetic is M<true>'s; sv.ops is then the full stream, not the fused list.
+template <bool NEED_UV, int FUSE, bool X = false>
+__global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
                                                                       uint32_t max_depth, double *lx, double *ly,
                                                                       double *lz, uint32_t *counts, uint32_t flags,
                                                                       uint32_t refill_at, uint32_t chunk) {
@@ -1659,11 +1679,17 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_path_pool(SceneView 
         segments += (uint32_t)__popcll(__ballot(has));
         double ht;
         int32_t id;
-        extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along
+        if constexpr (X) {
+            unsigned long long unused_nodes = 0, unused_prims = 0;
+            extend_scan_walk<true, true, FUSE == 2, false>(sv, o, d, time, pkey, depth, 0.001, kF64Max, has, false, ht, id,
+                                                           unused_nodes, unused_prims);
+        } else {
+            extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along
+        }
         if (has) {
             const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
             D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
-            const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
+            const bool alive = shade_vertex<X, NEED_UV, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
                                                                         id, depth, max_depth, flags, lx, ly, lz, no, nd,
                                                                         nbeta, &c);
             // the per-path sum of the other forms: the first vertex is stored, later ones are added unless zero
@@ -2061,6 +2087,7 @@ struct pt_ctx {
     uint32_t tree_tuning[4] = {16, 16, 32, 4}; // refill at / inner min / shade min / traversing min
     void *d_pool_consts = nullptr;
     std::deque<PoolConsts> h_pool_consts; // host copies of the passes in flight (cleared at every stream synchronisation of a render)
+    bool exact_pool = true;       // exact mode uses the path pool too (short streams)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
@@ -2312,6 +2339,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // (realtime frames, 0.4 M paths after the pixel skip, measured 16 % slower through the pool than through the
     // persistent form below: four of five generated samples are skipped)
     const bool pool = fused && ctx->path_pool && !realtime;
+    // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
+    const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
+                       ctx->view.n_leaves <= kLdsLeaves;
     const bool tree = !fused && !realtime && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count;
     const bool persistent = fused && !pool && ctx->persistent && n <= ctx->persistent_max_paths;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
@@ -2325,7 +2355,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         ctx->h_pool_consts.emplace_back(PoolConsts{ctx->cam, pp}); // must outlive the asynchronous copy
         return hipMemcpyAsync(ctx->d_pool_consts, &ctx->h_pool_consts.back(), sizeof(PoolConsts), hipMemcpyHostToDevice, st);
     };
-    if (pool || tree) {
+    if (pool || tree || xpool) {
         // no ray generation launch: the pool kernels make their own camera samples
     } else if (gen0) {
         SceneView v = ctx->view;
@@ -2370,9 +2400,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         else launch(k_trace_persistent<false, 1>);
         HIP_TRY(ctx, mark());
     }
-    if (pool) {
+    if (pool || xpool) {
         const uint32_t tiles = (n + 63u) / 64u;
-        const uint32_t resident = (uint32_t)ctx->n_cu * PT_SHADE_WAVES * ctx->pool_grid;
+        const uint32_t resident = (uint32_t)ctx->n_cu * (xpool ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         // a small pass is cut into at least four chunks per wave so that the waves finish together
         const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
@@ -2390,7 +2420,13 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
                                ctx->pool_refill, chunk);
         };
-        if (media && ctx->need_uv) launch(k_path_pool<true, 2>);
+        if (xpool) {
+            v = ctx->view; // the reference's own tree
+            if (media && ctx->need_uv) launch(k_path_pool<true, 2, true>);
+            else if (media) launch(k_path_pool<false, 2, true>);
+            else if (ctx->need_uv) launch(k_path_pool<true, 1, true>);
+            else launch(k_path_pool<false, 1, true>);
+        } else if (media && ctx->need_uv) launch(k_path_pool<true, 2>);
         else if (media) launch(k_path_pool<false, 2>);
         else if (ctx->need_uv) launch(k_path_pool<true, 1>);
         else launch(k_path_pool<false, 1>);
@@ -2419,7 +2455,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         else launch(k_tree_pool<false, false>);
         HIP_TRY(ctx, mark());
     }
-    const bool one_launch = persistent || pool || tree;
+    const bool one_launch = persistent || pool || tree || xpool;
     for (uint32_t d = one_launch ? iters : 0; d < iters; ++d) {
         const Queue &qi = ctx->q[d & 1];
         const Queue &qo = ctx->q[(d + 1) & 1];
@@ -2449,11 +2485,11 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
     ctx->stats.paths += n;
-    ctx->stats.launches_raygen += (gen0 || pool || tree) ? 0 : 1;
-    ctx->stats.launches_extend += (fused || tree) ? 0 : iters;
+    ctx->stats.launches_raygen += (gen0 || pool || tree || xpool) ? 0 : 1;
+    ctx->stats.launches_extend += (fused || tree || xpool) ? 0 : iters;
     ctx->stats.launches_shade += one_launch ? 1 : (gen0 ? iters - 1 : iters);
     ctx->stats.launches_resolve += 1;
-    ctx->stats.last_pass_form = tree ? PT_PASS_TREE_POOL : pool ? PT_PASS_PATH_POOL : persistent ? PT_PASS_PERSISTENT
+    ctx->stats.last_pass_form = tree ? PT_PASS_TREE_POOL : (pool || xpool) ? PT_PASS_PATH_POOL : persistent ? PT_PASS_PERSISTENT
                                 : fused ? PT_PASS_PER_BOUNCE_FUSED : PT_PASS_PER_BOUNCE;
     if (profile || (read_counts && !one_launch)) { // the one-launch forms size no grids from the counts
         ctx->h_shard_counts.resize((size_t)(iters + 1) * kShards);
@@ -2530,6 +2566,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
         if (std::sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
             for (int k = 0; k < 4; ++k) ctx->tree_tuning[k] = std::min(255u, std::max(k == 3 ? 0u : 1u, v[k]));
     }
+    if (const char *e = std::getenv("PTGPU_EXACT_POOL")) ctx->exact_pool = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_PATH_POOL")) ctx->path_pool = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_POOL_REFILL")) ctx->pool_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("PTGPU_POOL_CHUNK")) ctx->pool_chunk = (uint32_t)std::min(1l << 20, std::max(64l, std::strtol(e, nullptr, 10)));

@@ -246,3 +246,32 @@ def test_tree_pool_gives_the_same_image(name, param):
         assert st_b.launches_extend == 0 and st_b.launches_raygen == 0, env
         assert np.array_equal(a, b, equal_nan=True), env
         assert int(st_a.segments) == int(st_b.segments), env
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke"])
+def test_exact_mode_pool_gives_the_same_image(name):
+    """Exact mode on short op streams: one pool launch per pass around the wave-uniform walk of the reference's own
+    tree against ray generation plus an extend and a shade launch per bounce. Bit-identical images."""
+    scene = ptgpu.Scene.named(name, 1.0)
+    w = h = 96
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            ctx = _ctx(max_paths_in_flight=1 << 16, flags=ptgpu.PT_CFG_EXACT)
+            ctx.upload(scene)
+            ctx.render(w, h, 12, 50)
+            img, st = ctx.readback(), ctx.stats()
+            ctx.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return img, st
+
+    a, st_a = run({"PTGPU_EXACT_POOL": "0"})
+    b, st_b = run({})
+    assert st_a.launches_extend > 0 and st_b.launches_extend == 0
+    assert int(st_b.last_pass_form) == ptgpu.PT_PASS_PATH_POOL
+    assert np.array_equal(a, b, equal_nan=True)
+    assert int(st_a.segments) == int(st_b.segments)
