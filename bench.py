@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--scene-param", type=int, default=0, help="recipe parameter (sphere_cloud: sphere count)")
-    ap.add_argument("--paths-in-flight", type=int, default=1 << 26)
+    ap.add_argument("--paths-in-flight", type=int, default=1 << 28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode side measurement")
     ap.add_argument("--realtime", action="store_true",
