@@ -1,0 +1,321 @@
+// The path pool kernels: one launch per offline pass, a path in one lane's registers from camera sample to last vertex.
+// Part of ptgpu.hip (included inside its unnamed namespace, in this order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------------------
+// Path pool form of the fused pipeline: ONE launch traces a whole offline pass and no path ever visits HBM. A wave is
+// a pool of 64 path slots over its own run of the pass's path ids: every round all 64 lanes walk the primitive list,
+// the lanes that hold a path shade their vertex and keep the next ray, throughput and radiance sum in registers; a
+// path that ends stores its radiance, and once enough slots are free the free lanes generate the next camera samples
+// of the run (ballot + prefix count; the run belongs to this wave alone). Queue entries, their compaction and the
+// launch per bounce are gone; what crosses HBM per PATH is the 24-B radiance the resolve kernel reads. Same camera
+// arithmetic and draws as k_raygen, same vertex code, same order of the per-path sum: images are bit-identical to
+// the other forms.
+// ------------------------------------------------------------------------------------------------------------
+// Camera and pass constants of the pool kernel, read from memory where camera samples are made: as kernel arguments
+// they would sit in some sixty scalar registers for the whole kernel, which the walk and the shading need themselves.
+struct PoolConsts {
+    CameraDev cam;
+    PassParams pp;
+};
+struct PoolLds {
+    LdsLeaf leaves[kLdsLeaves];
+    // camera samples made 64 at a time by the whole wave and handed to lanes as they fall free
+    double cam_ray[kWavesPerBlock][7][64]; // origin, direction, time
+    uint64_t cam_key[kWavesPerBlock][64];
+    uint32_t cam_rn[kWavesPerBlock][64];
+    uint32_t cam_pid[kWavesPerBlock][64];
+};
+#ifndef PT_EXACT_POOL_WAVES
+#define PT_EXACT_POOL_WAVES 3 // measured on the Cornell box: 1 -> 895, 2 -> 1506, 3 -> 1786, 4 -> 1704 Mpaths/s
+#endif
+// X: exact mode. The walk is the wave-uniform scan of the reference's own threaded tree (every box test, the
+// reference's order), the arithmetic is M<true>'s; sv.ops is then the full stream, not the fused list.
+template <bool NEED_UV, int FUSE, bool X = false>
+__global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
+                                                                      uint32_t max_depth, double *lx, double *ly,
+                                                                      double *lz, uint32_t *counts, uint32_t flags,
+                                                                      uint32_t refill_at, uint32_t chunk) {
+    __shared__ PoolLds S;
+    {
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        __syncthreads(); // the only barrier of the kernel
+    }
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // Path ids are handed out in chunks from one counter (the first slot past the bounce rows of counts[], zero at
+    // launch and left out of the segment sum): a wave takes the next chunk when its current one is used up, so every
+    // wave stays full until the pass itself runs out of paths.
+    uint32_t cur = 0, end = 0, stash_n = 0;
+    bool exhausted = false;
+    bool has = false;
+    D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), beta = d3(0.0, 0.0, 0.0), sum = d3(0.0, 0.0, 0.0);
+    double time = 0.0;
+    uint64_t pkey = 0;
+    uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
+    for (;;) {
+        bool drained = false;
+        for (;;) { // hand camera samples to free lanes
+            const unsigned long long idle = __ballot(!has);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle < refill_at) break;
+            if (stash_n == 0) {
+                if (cur >= end && !exhausted) {
+                    uint32_t first = 0;
+                    if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
+                    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                    exhausted = first >= n;
+                    cur = min(first, n);
+                    end = min(cur + chunk, n); // chunk is far below 2^32 - n
+                }
+                if (cur >= end) { // the pass has no more paths to start
+                    drained = n_idle == 64;
+                    break;
+                }
+                // the next (up to) 64 camera samples, one per lane, parked in LDS
+                const PoolConsts *pc = consts;
+                asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+                const CameraDev cam = pc->cam;
+                const PassParams pp = pc->pp;
+                const uint32_t m = min(64u, end - cur);
+                const bool fresh = lane < m;
+                const uint32_t id = cur + lane;
+                uint32_t i = 0, jy = 0, smp = 0;
+                uint64_t pixel = 0;
+                if (fresh) {
+                    const uint32_t p = id % pp.cpix;
+                    smp = id / pp.cpix;
+                    i = pp.cx0 + p % pp.cw;
+                    jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+                    pixel = (uint64_t)jy * pp.width + i;
+                }
+                const unsigned long long made = __ballot(fresh);
+                if (fresh) {
+                    const uint32_t k = (uint32_t)__popcll(made & ((1ull << lane) - 1ull));
+                    Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + smp), 0};
+                    double random = g.next(); // src/trace.rs:153-156
+                    const double u = ((double)i + random) / (double)pp.width;
+                    random = g.next();
+                    const double v = ((double)jy + random) / (double)pp.height;
+                    const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+                    const D3 offset = cam.u * rd.x + cam.v * rd.y;
+                    const double t = cam.time0 + g.next() * (cam.time1 - cam.time0);
+                    const D3 dir = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+                    const D3 org = cam.origin + offset;
+                    S.cam_ray[wv][0][k] = org.x; S.cam_ray[wv][1][k] = org.y; S.cam_ray[wv][2][k] = org.z;
+                    S.cam_ray[wv][3][k] = dir.x; S.cam_ray[wv][4][k] = dir.y; S.cam_ray[wv][5][k] = dir.z;
+                    S.cam_ray[wv][6][k] = t;
+                    S.cam_key[wv][k] = g.key;
+                    S.cam_rn[wv][k] = g.n;
+                    S.cam_pid[wv][k] = id;
+                }
+                stash_n = (uint32_t)__popcll(made);
+                cur += m;
+            }
+            const uint32_t take = min(n_idle, stash_n);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has && rank < take) {
+                const uint32_t k = stash_n - 1u - rank;
+                pid = S.cam_pid[wv][k];
+                o = d3(S.cam_ray[wv][0][k], S.cam_ray[wv][1][k], S.cam_ray[wv][2][k]);
+                d = d3(S.cam_ray[wv][3][k], S.cam_ray[wv][4][k], S.cam_ray[wv][5][k]);
+                time = S.cam_ray[wv][6][k];
+                pkey = S.cam_key[wv][k];
+                rn = S.cam_rn[wv][k];
+                beta = d3(1.0, 1.0, 1.0);
+                depth = 0;
+                has = true;
+            }
+            stash_n -= take;
+        }
+        if (drained) break; // nothing in flight, nothing left to start
+        segments += (uint32_t)__popcll(__ballot(has));
+        double ht;
+        int32_t id;
+        if constexpr (X) {
+            unsigned long long unused_nodes = 0, unused_prims = 0;
+            extend_scan_walk<true, true, FUSE == 2, false>(sv, o, d, time, pkey, depth, 0.001, kF64Max, has, false, ht, id,
+                                                           unused_nodes, unused_prims);
+        } else {
+            extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along
+        }
+        if (has) {
+            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
+            D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
+            const bool alive = shade_vertex<X, NEED_UV, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
+                                                                        id, depth, max_depth, flags, lx, ly, lz, no, nd,
+                                                                        nbeta, &c);
+            // the per-path sum of the other forms: the first vertex is stored, later ones are added unless zero
+            if (depth == 0) sum = c;
+            else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+            if (alive) {
+                o = no;
+                d = nd;
+                beta = nbeta;
+                depth += 1;
+            } else {
+                lx[pid] = sum.x;
+                ly[pid] = sum.y;
+                lz[pid] = sum.z;
+                has = false;
+            }
+        }
+    }
+    if (lane == 0 && segments) atomicAdd(&counts[0], segments); // the pass's segment count, for the statistics
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The path pool for scenes that are traced through the SAH tree: one launch per offline pass, a path in one lane's
+// registers from camera sample to last vertex, no queues. A lane is free, on an inner node, on a leaf, or waiting
+// with a finished traversal. Every round steps the traversing lanes (inner nodes first, then leaves, as in
+// k_extend_accel_pool), and once enough lanes wait (or too few still traverse) the waiting lanes shade their vertex
+// together and start their next ray; free lanes take new camera samples from the pass's chunk counter.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef PT_TREE_UV_WAVES
+#define PT_TREE_UV_WAVES 2 // waves per SIMD of the textured variants: their shading is the largest code here (4: 638, 3: 640, 2: 730 Mpaths/s on the final scene)
+#endif
+template <bool NEED_UV, bool MEDIA>
+__global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
+                                                                      const PoolConsts *consts, uint32_t n, uint32_t max_depth,
+                                                                      double *lx, double *ly, double *lz, uint32_t *counts,
+                                                                      uint32_t flags, uint32_t tuning, uint32_t chunk) {
+    __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
+    const uint32_t refill_at = tuning & 0xffu, inner_min = (tuning >> 8) & 0xffu, shade_min = (tuning >> 16) & 0xffu,
+                   trav_min = tuning >> 24;
+    constexpr int32_t kDone = INT32_MIN; // never a leaf reference
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+    bool has = false;
+    D3 o = d3(0, 0, 0), d = d3(0, 0, 1), inv = o, beta = o, sum = o;
+    double time = 0.0, closest = 0.0;
+    uint64_t pkey = 0;
+    uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
+    int32_t best = -1, node = kDone;
+    int sp = 0;
+    auto start_ray = [&]() { // (o, d) hold a new ray
+        inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+        closest = kF64Max;
+        best = -1;
+        sp = 0;
+        // rays with a NaN or infinite component are not traced (see k_extend_accel)
+        const double probe = (o.x + o.y + o.z) + (d.x + d.y + d.z);
+        node = (probe == probe && fabs(probe) <= kF64Max) ? 0 : kDone;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle >= refill_at) {
+            if (cur >= end && !exhausted) {
+                uint32_t first = 0;
+                if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
+                first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                exhausted = first >= n;
+                cur = min(first, n);
+                end = min(cur + chunk, n);
+            }
+            if (cur < end) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!has && cur + rank < end) {
+                    const PoolConsts *pc = consts;
+                    asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+                    const CameraDev cam = pc->cam;
+                    const PassParams pp = pc->pp;
+                    pid = cur + rank;
+                    const uint32_t p = pid % pp.cpix, s = pid / pp.cpix;
+                    const uint32_t i = pp.cx0 + p % pp.cw;
+                    const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+                    const uint64_t pixel = (uint64_t)jy * pp.width + i;
+                    Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
+                    double random = g.next(); // src/trace.rs:153-156
+                    const double u = ((double)i + random) / (double)pp.width;
+                    random = g.next();
+                    const double v = ((double)jy + random) / (double)pp.height;
+                    const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+                    const D3 offset = cam.u * rd.x + cam.v * rd.y;
+                    time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+                    d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+                    o = cam.origin + offset;
+                    beta = d3(1.0, 1.0, 1.0);
+                    pkey = g.key;
+                    rn = g.n;
+                    depth = 0;
+                    has = true;
+                    start_ray();
+                }
+                cur = min(cur + n_idle, end);
+            } else if (n_idle == 64) {
+                break; // nothing in flight, nothing left to start
+            }
+        }
+        // traversal: inner nodes for as long as at least `inner_min` lanes are on one, then the leaves
+        for (;;) {
+            if (has && node >= 0) {
+                const AccelNode &nd = nodes[node];
+                double t0, t1;
+                const bool h0 = accel_box(nd.lo[0], nd.hi[0], o, inv, 0.001, closest, t0);
+                const bool h1 = accel_box(nd.lo[1], nd.hi[1], o, inv, 0.001, closest, t1);
+                const int32_t c0 = nd.child[0], c1 = nd.child[1];
+                if (h0 && h1) {
+                    const bool first0 = t0 <= t1;
+                    stack[sp++][threadIdx.x] = first0 ? c1 : c0;
+                    node = first0 ? c0 : c1;
+                } else if (h0 || h1) {
+                    node = h0 ? c0 : c1;
+                } else {
+                    node = sp ? stack[--sp][threadIdx.x] : kDone;
+                }
+            }
+            const uint32_t n_inner = (uint32_t)__popcll(__ballot(has && node >= 0));
+            if (n_inner == 0 || n_inner < inner_min) break;
+        }
+        if (has && node < 0 && node != kDone) {
+            const int32_t ref = ~node;
+            const int32_t first = ref >> 3, count = ref & 7;
+            for (int32_t k = first; k < first + count; ++k) {
+                const DevOp op = prims[k];
+                double t = 0.0;
+                int sub = 0;
+                bool hit;
+                if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
+                    hit = medium_hit<false>(sv, op, o, d, inv, time, 0.001, closest, pkey, depth, t);
+                else hit = prim_hit<false>(sv, op, o, d, inv, time, 0.001, closest, t, sub);
+                if (hit) {
+                    closest = t;
+                    best = op.leaf | (sub << 28);
+                }
+            }
+            node = sp ? stack[--sp][threadIdx.x] : kDone;
+        }
+        // vertices: when enough lanes wait with a finished traversal, or too few are still traversing to go on
+        const bool ready = has && node == kDone;
+        const uint32_t n_ready = (uint32_t)__popcll(__ballot(ready));
+        const uint32_t n_trav = (uint32_t)__popcll(__ballot(has && node != kDone));
+        if (n_ready && (n_ready >= shade_min || n_trav <= trav_min)) {
+            segments += n_ready;
+            if (ready) {
+                const int32_t li = best < 0 ? 0 : (best & 0x0fffffff);
+                D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
+                const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
+                                                                            closest, best, depth, max_depth, flags, lx, ly,
+                                                                            lz, no, nd, nbeta, &c);
+                if (depth == 0) sum = c; // the per-path sum of the other forms
+                else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+                if (alive) {
+                    o = no;
+                    d = nd;
+                    beta = nbeta;
+                    depth += 1;
+                    start_ray();
+                } else {
+                    lx[pid] = sum.x;
+                    ly[pid] = sum.y;
+                    lz[pid] = sum.z;
+                    has = false;
+                }
+            }
+        }
+    }
+    if (lane == 0 && segments) atomicAdd(&counts[0], segments);
+}

@@ -1,0 +1,492 @@
+// One path vertex (the body of `color`, src/trace.rs:198-234) and the queue-based pass forms built on it: a launch per bounce, bounce 0 with its own rays, persistent waves.
+// Part of ptgpu.hip (included inside its unnamed namespace, in this order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------------------
+// shade + compaction
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz, uint32_t pid, D3 c) {
+    // Adding an exact zero changes nothing; a NaN compares unequal to zero and is added, which keeps the
+    // reference's NaN propagation (0 * x / 0 in src/trace.rs:217-220).
+    // A path id belongs to one lane of one launch at a time, so the hardware f64 add in L2 gives the same sum as a
+    // load / add / store here, without making the wave wait for the load.
+    if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) {
+        unsafeAtomicAdd(&lx[pid], c.x);
+        unsafeAtomicAdd(&ly[pid], c.y);
+        unsafeAtomicAdd(&lz[pid], c.z);
+    }
+}
+
+// One path vertex: the body of `color` (src/trace.rs:198-234) for a ray whose closest hit is (ht, id), id < 0 for a
+// miss. `lf` is the hit primitive's leaf record (fields are fetched where they are used; any record when id < 0).
+// Adds the vertex's radiance to the path's accumulator and, if the path goes on, returns true with the next ray,
+// throughput and RNG draw count.
+// FIRST: the vertex is the path's first one and nothing has initialised the path's accumulator: the vertex's
+// radiance (every branch adds at most once) is stored, zero included, instead of added.
+// RETURN: the vertex's radiance is handed back in `vertex_radiance` and nothing is written (the caller keeps the
+// path's sum).
+enum RadianceMode { RAD_ADD = 0, RAD_FIRST = 1, RAD_RETURN = 2 };
+template <bool X, bool NEED_UV, int FIRST = RAD_ADD>
+__device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, D3 beta,
+                                             uint64_t pkey, uint32_t pid, uint32_t &rn, double ht, int32_t id,
+                                             uint32_t depth, uint32_t max_depth, uint32_t flags, double *lx, double *ly,
+                                             double *lz, D3 &no, D3 &nd, D3 &nbeta, D3 *vertex_radiance = nullptr) {
+    bool alive = false;
+    D3 first = d3(0.0, 0.0, 0.0);
+    auto add_radiance = [&](double *ax, double *ay, double *az, uint32_t path, D3 c) {
+        if constexpr (FIRST != RAD_ADD) first = c;
+        else ::add_radiance(ax, ay, az, path, c);
+    };
+    if (id < 0) {
+        // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
+        add_radiance(lx, ly, lz, pid, beta * 0.0);
+    } else {
+        Rng g{pkey, rn};
+        const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, ht, (id >> 28) & 7);
+        const D3 emissive = emitted(sv, lf, d, rec);
+        bool done = true, dead = false;
+        if (depth < max_depth) {
+            if (lf.mat_kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
+                D3 outward_normal;
+                D3 reflected = reflect<X>(d, rec.n);
+                double ni_over_nt, reflect_prob, cosine;
+                D3 refracted = d3(0.0, 0.0, 0.0);
+                const double d_dot_n = M<X>::dot(d, rec.n);
+                if (d_dot_n > 0.0) {
+                    outward_normal = -rec.n;
+                    ni_over_nt = lf.ref_idx;
+                    cosine = M<X>::div(lf.ref_idx * d_dot_n, M<X>::length(d));
+                } else {
+                    outward_normal = rec.n;
+                    ni_over_nt = M<X>::rcp(lf.ref_idx);
+                    cosine = M<X>::div(-d_dot_n, M<X>::length(d));
+                }
+                if (refract<X>(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick<X>(cosine, lf.ref_idx);
+                else reflect_prob = 1.0;
+                nd = (g.next() < reflect_prob) ? reflected : refracted;
+                no = rec.p;
+                nbeta = beta * d3(1.0, 1.0, 1.0); // specular: albedo * color(next), no emission (trace.rs:209-211)
+                done = false;
+            } else if (lf.mat_kind == PT_M_METAL) { // src/material.rs:230-241
+                D3 reflected = reflect<X>(M<X>::unit_vector(d), rec.n);
+                nd = reflected + lf.fuzz * random_in_unit_sphere(g);
+                no = rec.p;
+                nbeta = beta * d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
+                done = false;
+            } else if (lf.mat_kind == PT_M_LAMBERTIAN || lf.mat_kind == PT_M_ISOTROPIC) {
+                const bool lambert = lf.mat_kind == PT_M_LAMBERTIAN;
+                // scatter(): src/material.rs:289-301 (Lambertian), 347-351 (Isotropic draws a sphere sample it never uses)
+                // With PT_RENDER_BOOK_SEMANTICS that sample is the scattered direction and the pdf is the
+                // uniform sphere's, 1/(4 pi) (unit_sphere_pdf, src/material.rs:46-48).
+                const bool book = (flags & PT_RENDER_BOOK_SEMANTICS) != 0 && !lambert;
+                D3 iso_dir = d3(0.0, 0.0, 0.0);
+                if (!lambert) {
+                    const D3 sample = random_in_unit_sphere(g);
+                    if (book) iso_dir = sample;
+                }
+                const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
+                const D3 albedo = leaf_texture(sv, lf, rec);
+                add_radiance(lx, ly, lz, pid, beta * emissive);
+#ifndef PT_F64_WEIGHTS
+#define PT_F64_WEIGHTS 0
+#endif
+                if constexpr (X || PT_F64_WEIGHTS) {
+                    Onb uvw;
+                    if (lambert) uvw = onb_from_w<X>(rec.n);
+                    // MixturePDF::generate, src/material.rs:427-433
+                    D3 dir;
+                    if (g.next() < 0.5) dir = lights_random<X>(sv, g, rec.p);
+                    else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : iso_dir;
+                    // MixturePDF::value, src/material.rs:424-426
+                    const D3 unit_dir = M<X>::unit_vector(dir);
+                    double own = iso_pdf;
+                    if (lambert) { // CosinePDF::value, src/material.rs:375-382
+                        double cosine = M<X>::dot(unit_dir, uvw.w);
+                        own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
+                    }
+                    const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir) + 0.5 * own;
+                    double spdf = iso_pdf;
+                    if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
+                        double cosine = M<X>::dot(rec.n, unit_dir);
+                        spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
+                    }
+                    // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
+                    nbeta = M<X>::divs(beta * (albedo * spdf), pdf_val);
+                    nd = dir;
+                    if constexpr (!X) { // fast mode: see the f32 form below
+                        const bool below = lambert && spdf == 0.0;
+                        if (below) nbeta = d3(0.0, 0.0, 0.0);
+                        dead = below && !sv.has_isotropic;
+                    }
+                } else {
+                    // same estimator with the weights in f32 (see "f32 radiometry" in pt_device.h)
+                    const F3 nf = to_f3(rec.n);
+                    OnbF uvw;
+                    if (lambert) uvw = onbf_from_w(nf);
+                    D3 dir;
+                    if (g.next() < 0.5) {
+                        const double x = (double)sv.n_lights * g.next(); // HitableList::random, hitable.rs:74-77
+                        dir = light_random_fast(sv.lights[(int)x], g, rec.p);
+                    } else {
+                        dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(g))) : iso_dir;
+                    }
+                    const F3 dirf = to_f3(dir);
+                    const float len2 = dotf(dirf, dirf);
+                    const F3 unit_dir = dirf * __builtin_amdgcn_rsqf(len2);
+                    float own = (float)iso_pdf, spdf = (float)iso_pdf;
+                    if (lambert) {
+                        const float cw = dotf(unit_dir, uvw.w);
+                        own = cw > 0.0f ? cw * 0.31830988618379067154f : 0.0f;
+                        const float cn = dotf(nf, unit_dir);
+                        spdf = cn < 0.0f ? 0.0f : cn * 0.31830988618379067154f;
+                    }
+                    const float weight = __builtin_amdgcn_rcpf((float)sv.n_lights);
+                    float lsum = 0.0f;
+                    for (int k = 0; k < sv.n_lights; ++k)
+                        lsum += weight * light_pdf_value_fast(sv.lights[k], rec.p, dirf, len2);
+                    const float pdf_val = 0.5f * lsum + 0.5f * own;
+                    const float inv_pdf = __builtin_amdgcn_rcpf(pdf_val);
+                    // Isotropic: 0 * x / 0 must stay NaN (src/trace.rs:217-220): rcp(0) = inf, 0 * inf = NaN.
+                    // Lambertian: a direction below the surface has scattering_pdf 0 and its sample weighs
+                    // nothing. In f64 the mixture pdf is then still positive (the direction came from a
+                    // light); in f32 a grazing light sample can also miss its light by rounding, which
+                    // would turn 0 / pdf into 0 / 0, so the weight is pinned to the 0 the reference gets.
+                    const bool below = lambert && spdf == 0.0f; // a NaN spdf is not "below": it propagates
+                    const float wr = below ? 0.0f : ((float)albedo.x * spdf) * inv_pdf;
+                    const float wg = below ? 0.0f : ((float)albedo.y * spdf) * inv_pdf;
+                    const float wb = below ? 0.0f : ((float)albedo.z * spdf) * inv_pdf;
+                    nbeta = beta * d3((double)wr, (double)wg, (double)wb);
+                    nd = dir;
+                    // A path whose throughput is exactly 0 can only add 0 * (finite radiance) from here on;
+                    // without Isotropic materials nothing downstream turns that into NaN, so it stops here.
+                    dead = below && !sv.has_isotropic;
+                }
+                no = rec.p;
+                done = false;
+            }
+        }
+        if (done) add_radiance(lx, ly, lz, pid, beta * emissive); // src/trace.rs:225
+        alive = !done && !dead;
+        rn = g.n;
+    }
+    if constexpr (FIRST == RAD_FIRST) {
+        lx[pid] = first.x;
+        ly[pid] = first.y;
+        lz[pid] = first.z;
+    }
+    if constexpr (FIRST == RAD_RETURN) *vertex_radiance = first;
+    return alive;
+}
+
+// FUSE = 0: hits come from the extend kernel through hit_t / hit_id.
+// FUSE = 1 / 2: the scene is a short box-free op list (2: with media); the ray is traced right here before it is
+// shaded, so the extend launch, its re-read of the ray and the hit round trip through HBM disappear. The op list is
+// passed in sv.ops / sv.n_traversal_ops.
+// A leaf record padded to 200 B: with a stride of 50 dwords the same field of different leaves spreads over 16 LDS
+// banks instead of 2.
+struct LdsLeaf {
+    DevLeaf l;
+    double pad;
+};
+constexpr int kLdsLeaves = 32; // the fused kernels keep the whole leaf table in LDS
+
+// LDS of one workgroup. Kept as ONE object: with a second __shared__ object beside a buffer that direct-to-LDS loads
+// fill, the compiler waits for those loads before every LDS read.
+template <int FUSE> struct ShadeLds {
+    uint32_t cnt[kWavesPerBlock + 1];
+    LdsLeaf leaves[1];
+    unsigned char tile[1][16];
+};
+template <> struct ShadeLds<1> {
+    alignas(16) unsigned char tile[kWavesPerBlock][Queue::kTileBytes]; // each wave's next queue tile
+    LdsLeaf leaves[kLdsLeaves];
+    uint32_t cnt[kWavesPerBlock + 1];
+};
+
+// Starts the copy of queue tile `tile` into the calling wave's LDS buffer: six 1-KiB direct-to-LDS loads (lane l
+// moves bytes [16 l, 16 l + 16) of every KiB; the instruction offset advances the global and the LDS address alike).
+// Nothing waits here. The loads are written in assembly on purpose: told about them, the compiler drains the VM
+// counter before EVERY later LDS read (it cannot tell the tile buffer from the leaf table), which would put the
+// whole HBM round trip back in front of the shading. The caller retires them with tile_wait() before it reads the
+// buffer.
+__device__ __forceinline__ void prefetch_tile(const Queue &q, uint32_t tile, unsigned char *lds_wave, uint32_t lane) {
+    typedef __attribute__((address_space(3))) unsigned char *LPtr;
+    const char *g0 = q.base + (size_t)tile * Queue::kTileBytes + lane * 16u;
+    const char *g1 = g0 + 4096;
+    const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(LPtr)lds_wave);
+    const uint32_t l1 = l0 + 4096u;
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:3072\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 :
+                 : "v"(g0), "v"(g1), "s"(l0), "s"(l1)
+                 : "memory", "m0");
+}
+// Every vector memory operation of the wave, the tile copy included, has completed.
+__device__ __forceinline__ void tile_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <bool X, bool NEED_UV, int FUSE>
+__global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
+                                                  uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
+                                                  double *lx, double *ly, double *lz,
+                                                  uint32_t depth, uint32_t max_depth, uint32_t flags) {
+    __shared__ ShadeLds<(FUSE != 0) ? 1 : 0> S;
+    uint32_t *lds = S.cnt;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_virtual = ((max_shard_count(n_in, sh.shards) + kBlock - 1) / kBlock) << sh.shift;
+    // first queue tile of virtual chunk v that this wave handles
+    auto tile_of = [&](uint32_t v) -> uint32_t {
+        return (((v & (sh.shards - 1)) * sh.shard_cap + (v >> sh.shift) * kBlock) >> 6) + wave;
+    };
+    if constexpr (FUSE != 0) {
+        if (blockIdx.x < n_virtual) prefetch_tile(qi, tile_of(blockIdx.x), S.tile[wave], lane);
+        // Shading gathers ~100 B of its leaf per lane through a chain of dependent loads (kind -> geometry ->
+        // material); from LDS each link costs tens of cycles instead of an L1/L2 round trip.
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        tile_wait();
+        __syncthreads();
+    }
+    for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
+        const uint32_t s_id = v & (sh.shards - 1);
+        const uint32_t ns = shard_count(n_in, s_id);
+        const uint32_t row0 = (v >> sh.shift) * kBlock;
+        bool alive = false;
+        D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
+        double time = 0.0;
+        uint32_t pid = 0, rn = 0;
+        D3 o, d, beta;
+        double ht = 0.0;
+        int32_t id = -1;
+        uint64_t pkey = 0;
+        if constexpr (FUSE != 0) {
+            // This wave's tile was requested one iteration ago (or before the loop) and has had a whole trace + shade
+            // to arrive. Every field moves into registers, then the buffer is handed to the request for the tile of
+            // the next iteration, which the work below hides. Lanes past the shard's fill read stale entries: they
+            // are traced (whole waves walk the op list together) and dropped.
+            const unsigned char *e = S.tile[wave] + lane * 8u;
+            o = d3(*(const double *)(e + 0 * 512), *(const double *)(e + 1 * 512), *(const double *)(e + 2 * 512));
+            d = d3(*(const double *)(e + 3 * 512), *(const double *)(e + 4 * 512), *(const double *)(e + 5 * 512));
+            time = *(const double *)(e + 6 * 512);
+            beta = d3(*(const double *)(e + 7 * 512), *(const double *)(e + 8 * 512), *(const double *)(e + 9 * 512));
+            pkey = *(const uint64_t *)(e + 10 * 512);
+            pid = *(const uint32_t *)(S.tile[wave] + 5632 + lane * 4u);
+            rn = *(const uint32_t *)(S.tile[wave] + 5888 + lane * 4u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads are done before the buffer is refilled
+            const uint32_t vn = v + gridDim.x;
+            if (vn < n_virtual) prefetch_tile(qi, tile_of(vn), S.tile[wave], lane);
+        }
+        if (row0 >= ns) { // uniform for the workgroup
+            if constexpr (FUSE != 0) tile_wait();
+            continue;
+        }
+        const uint32_t local = row0 + threadIdx.x;
+        const uint32_t i = s_id * sh.shard_cap + local;
+        const uint32_t n = s_id * sh.shard_cap + ns; // first slot past this shard's entries
+        if (FUSE) {
+            extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
+#ifdef PT_EXPERIMENT_MISS
+            id = ht > 1e300 ? id : -1;
+#endif
+        }
+        if (i < n) {
+            if (!FUSE) {
+                o = d3(qi.ox(i), qi.oy(i), qi.oz(i));
+                d = d3(qi.dx(i), qi.dy(i), qi.dz(i));
+                time = qi.tm(i);
+                pid = qi.pid(i);
+                id = hit_id[i];
+                ht = hit_t[i];
+                beta = d3(qi.bx(i), qi.by(i), qi.bz(i));
+                rn = qi.rn(i);
+            }
+            if (!FUSE) pkey = qi.key(i);
+            const DevLeaf *lfp;
+            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
+            if constexpr (FUSE != 0) lfp = &S.leaves[li].l;
+            else lfp = &sv.leaves[li];
+            alive = shade_vertex<X, NEED_UV>(sv, *lfp, o, d, time, beta, pkey, pid, rn, ht, id, depth, max_depth, flags,
+                                             lx, ly, lz, no, nd, nbeta);
+        }
+        const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], lds);
+        // The next tile was requested a whole trace + shade ago; retiring it here, ahead of this iteration's stores,
+        // costs next to nothing, while a wait at the top of the loop would also sit out those stores.
+        if constexpr (FUSE != 0) tile_wait();
+        if (alive) {
+            qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
+            qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
+            qo.tm(slot) = time;
+            qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
+            qo.pid(slot) = pid;
+            qo.rn(slot) = rn;
+            qo.key(slot) = pkey;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Bounce 0 of an offline pass of a fused scene: the camera sample is generated, traced and shaded in one go, so the
+// first queue (96 B per path written by raygen and read back by the first shade launch) never exists. Same chunk
+// to shard mapping as k_raygen, same camera arithmetic, same draws.
+// ------------------------------------------------------------------------------------------------------------
+template <bool NEED_UV, int FUSE>
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_first_bounce(Queue qo, QueueShape sh, uint32_t *counts,
+                                                                         SceneView sv, CameraDev cam, PassParams pp,
+                                                                         double *lx, double *ly, double *lz,
+                                                                         uint32_t flags) {
+    __shared__ ShadeLds<1> S;
+    {
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        __syncthreads();
+    }
+    uint32_t *n_out = counts + kShards;
+    const uint32_t n = pp.cpix * pp.s_count;
+    const uint32_t n_chunks = (n + kBlock - 1) / kBlock;
+    for (uint32_t j = blockIdx.x; j < n_chunks; j += gridDim.x) {
+        const uint32_t s_id = j & (sh.shards - 1);
+        const uint32_t pid = j * kBlock + threadIdx.x;
+        const bool valid = pid < n;
+        const uint32_t pc = valid ? pid : 0u; // lanes past the end trace path 0 again and are dropped
+        const uint32_t p = pc % pp.cpix, s = pc / pp.cpix;
+        const uint32_t i = pp.cx0 + p % pp.cw;
+        const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+        const uint64_t pixel = (uint64_t)jy * pp.width + i;
+        Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
+        double random = g.next(); // src/trace.rs:153-156
+        const double u = ((double)i + random) / (double)pp.width;
+        random = g.next();
+        const double v = ((double)jy + random) / (double)pp.height;
+        const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
+        const D3 offset = cam.u * rd.x + cam.v * rd.y;
+        const double time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+        const D3 d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+        const D3 o = cam.origin + offset;
+        const D3 beta = d3(1.0, 1.0, 1.0);
+        uint32_t rn = g.n;
+        double ht;
+        int32_t id;
+        extend_list<FUSE == 2>(sv, sv.ops, o, d, time, g.key, 0u, 0.001, kF64Max, ht, id);
+        bool alive = false;
+        D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
+        if (valid) {
+            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
+            alive = shade_vertex<false, NEED_UV, RAD_FIRST>(sv, S.leaves[li].l, o, d, time, beta, g.key, pid, rn, ht, id, 0u,
+                                                       pp.max_depth, flags, lx, ly, lz, no, nd, nbeta);
+        }
+        const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], S.cnt);
+        if (alive) {
+            qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
+            qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
+            qo.tm(slot) = time;
+            qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
+            qo.pid(slot) = pid;
+            qo.rn(slot) = rn;
+            qo.key(slot) = g.key;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < sh.shards) {
+        // segments of bounce 0, per shard, as k_raygen counts them (statistics only: nothing reads a first queue)
+        const uint32_t k = threadIdx.x;
+        uint32_t fill = 0;
+        if (n_chunks > k) {
+            const uint32_t mine = (n_chunks - k + sh.shards - 1) >> sh.shift;
+            fill = mine * kBlock;
+            const uint32_t last = k + (mine - 1) * sh.shards;
+            if (last == n_chunks - 1) fill -= n_chunks * kBlock - n;
+        }
+        counts[k] = fill;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent form of the fused pipeline: ONE launch traces a whole pass. The pass's paths are dealt to the resident
+// waves in contiguous runs of queue tiles; a wave then carries its own paths through every bounce, compacting the
+// survivors into the same run of tiles of the other queue. A wave shares nothing with any other wave: no atomics on
+// shared counters, no barriers, no launch per bounce, and the tile prefetch runs on across bounces. The price is one
+// partly filled tile per wave and bounce, a few per cent of the tile steps. Which wave carries a path has no effect
+// on the path (its RNG is keyed by pixel and sample), so images are bit-identical to the launch-per-bounce form.
+// ------------------------------------------------------------------------------------------------------------
+template <bool NEED_UV, int FUSE>
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_trace_persistent(Queue qa, Queue qb, uint32_t *counts,
+                                                                             SceneView sv, double *lx, double *ly,
+                                                                             double *lz, uint32_t max_depth,
+                                                                             uint32_t flags) {
+    __shared__ ShadeLds<1> S;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    {
+        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
+        const double *src = (const double *)sv.leaves;
+        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
+            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
+        __syncthreads(); // the only barrier of the kernel
+    }
+    // this wave's run of tiles: the same in both queues
+    const uint32_t n_paths = shard_count(counts, 0); // raygen's fill of the first queue
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_tiles = (n_paths + 63u) >> 6;
+    const uint32_t per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const uint32_t first_tile = (blockIdx.x * kWavesPerBlock + wave) * per_wave;
+    uint32_t n = 0; // entries in this wave's run
+    if (first_tile < n_tiles) n = min(per_wave * 64u, n_paths - first_tile * 64u);
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    Queue qi = qa, qo = qb;
+    for (uint32_t depth = 0; depth <= max_depth && n > 0; ++depth) {
+        const uint32_t tiles = (n + 63u) >> 6;
+        uint32_t n_next = 0;
+        prefetch_tile(qi, first_tile, S.tile[wave], lane);
+        tile_wait();
+        for (uint32_t t = 0; t < tiles; ++t) {
+            const unsigned char *e = S.tile[wave] + lane * 8u;
+            const D3 o = d3(*(const double *)(e + 0 * 512), *(const double *)(e + 1 * 512), *(const double *)(e + 2 * 512));
+            const D3 d = d3(*(const double *)(e + 3 * 512), *(const double *)(e + 4 * 512), *(const double *)(e + 5 * 512));
+            const double time = *(const double *)(e + 6 * 512);
+            const D3 beta = d3(*(const double *)(e + 7 * 512), *(const double *)(e + 8 * 512), *(const double *)(e + 9 * 512));
+            const uint64_t pkey = *(const uint64_t *)(e + 10 * 512);
+            const uint32_t pid = *(const uint32_t *)(S.tile[wave] + 5632 + lane * 4u);
+            uint32_t rn = *(const uint32_t *)(S.tile[wave] + 5888 + lane * 4u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads are done before the buffer is refilled
+            if (t + 1 < tiles) prefetch_tile(qi, first_tile + t + 1, S.tile[wave], lane);
+            double ht;
+            int32_t id;
+            extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
+            bool alive = false;
+            D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
+            if (t * 64u + lane < n) { // lanes past the fill traced a stale entry; they are dropped here
+                const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
+                alive = shade_vertex<false, NEED_UV>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht, id, depth,
+                                                     max_depth, flags, lx, ly, lz, no, nd, nbeta);
+            }
+            const unsigned long long ballot = __ballot(alive);
+            const uint32_t slot = first_tile * 64u + n_next + __popcll(ballot & ((1ull << lane) - 1ull));
+            n_next += (uint32_t)__popcll(ballot);
+            tile_wait(); // the next tile has landed; see k_shade
+            if (alive) {
+                qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
+                qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
+                qo.tm(slot) = time;
+                qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
+                qo.pid(slot) = pid;
+                qo.rn(slot) = rn;
+                qo.key(slot) = pkey;
+            }
+        }
+        tile_wait(); // this bounce's entries are written before the next bounce reads them back
+        // segments of the next bounce, for the statistics (bounce 0 was counted by raygen)
+        if (lane == 0 && n_next) atomicAdd(&counts[(size_t)(depth + 1) * kShards], n_next);
+        const Queue tmp = qi;
+        qi = qo;
+        qo = tmp;
+        n = n_next;
+    }
+}
