@@ -1,13 +1,15 @@
 // Wavefront path tracer for gfx950 (MI355X) and its extern "C" entry points (include/ptgpu.h).
 //
-// The per-pixel recursion of TraceSceneBatchJob::trace / color (src/trace.rs:117-234) becomes four stages over
-// queues of path states held in HBM as structure-of-arrays:
-//   raygen   camera samples -> ray queue                      (src/trace.rs:152-158, src/camera.rs:53-59)
-//   extend   closest hit of every queued ray                  (Hitable::hit on SceneState.world, src/bvh.rs:74-99)
+// The per-pixel recursion of TraceSceneBatchJob::trace / color (src/trace.rs:117-234) becomes four stages:
+//   raygen   camera samples -> rays                           (src/trace.rs:152-158, src/camera.rs:53-59)
+//   extend   closest hit of every ray                         (Hitable::hit on SceneState.world, src/bvh.rs:74-99)
 //   shade    emitted / scatter / light sampling, next ray     (src/trace.rs:205-226, src/material.rs)
-//            + compaction of surviving paths into the next queue (wave64 ballot + LDS-staged block offsets)
+//            + compaction: free slots are refilled by wave64 ballot + prefix count
 //   resolve  per-pixel mean in sample order -> f32 RGBA image (src/trace.rs:166-182)
-// One pass traces `paths in flight` paths to completion: raygen, then (extend, shade) once per bounce.
+// One pass traces `paths in flight` paths to completion. Offline passes run the first three stages inside one kernel
+// whose waves keep 64 paths in registers (kernels_pool.h); realtime frames, ray batches and the forms kept for
+// comparison run them as launches over queues of path states in HBM (kernels_queue.h, kernels_extend.h,
+// kernels_shade.h). This file holds the context, the choice of form (run_pass) and the C entry points.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
