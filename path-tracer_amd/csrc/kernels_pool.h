@@ -34,8 +34,9 @@ template <bool NEED_UV, int FUSE, bool X = false>
 __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
                                                                       uint32_t max_depth, double *lx, double *ly,
                                                                       double *lz, uint32_t *counts, uint32_t flags,
-                                                                      uint32_t refill_at, uint32_t chunk) {
+                                                                      uint32_t refill_arg, uint32_t chunk) {
     __shared__ PoolLds S;
+    const uint32_t refill_at = min(max(refill_arg, 1u), 64u); // outside [1, 64] the loops below could not end
     {
         constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
         const double *src = (const double *)sv.leaves;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk) {
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
-    const uint32_t refill_at = tuning & 0xffu, inner_min = (tuning >> 8) & 0xffu, shade_min = (tuning >> 16) & 0xffu,
+    const uint32_t refill_at = min(max(tuning & 0xffu, 1u), 64u), inner_min = (tuning >> 8) & 0xffu, shade_min = (tuning >> 16) & 0xffu,
                    trav_min = tuning >> 24;
     constexpr int32_t kDone = INT32_MIN; // never a leaf reference
     const uint32_t lane = threadIdx.x & 63u;

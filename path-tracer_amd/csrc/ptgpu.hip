@@ -582,7 +582,8 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (const char *e = std::getenv("PTGPU_TREE_TUNING")) { // "refill,inner,shade,trav"
         unsigned v[4];
         if (std::sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
-            for (int k = 0; k < 4; ++k) ctx->tree_tuning[k] = std::min(255u, std::max(k == 3 ? 0u : 1u, v[k]));
+            for (int k = 0; k < 4; ++k) // a refill threshold above 64 would never be met: the kernel could not end
+                ctx->tree_tuning[k] = std::min(64u, std::max(k == 3 ? 0u : 1u, v[k]));
     }
     if (const char *e = std::getenv("PTGPU_EXACT_POOL")) ctx->exact_pool = std::strtol(e, nullptr, 10) != 0;
     if (const char *e = std::getenv("PTGPU_PATH_POOL")) ctx->path_pool = std::strtol(e, nullptr, 10) != 0;
