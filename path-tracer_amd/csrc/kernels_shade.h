@@ -123,12 +123,15 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     OnbF uvw;
                     if (lambert) uvw = onbf_from_w(nf);
                     D3 dir;
-                    if (g.next() < 0.5) {
-                        const double x = (double)sv.n_lights * g.next(); // HitableList::random, hitable.rs:74-77
-                        dir = light_random_fast(sv.lights[(int)x], g, rec.p);
-                    } else {
-                        dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(g))) : iso_dir;
-                    }
+                    // MixturePDF::generate (src/material.rs:427-433). Every sampler a lane can end up in takes its
+                    // next two draws (or none): their bits are made once, by all lanes together, before the lanes
+                    // part ways, instead of once per branch by the lanes of that branch.
+                    const bool to_light = g.next() < 0.5;
+                    int which = 0;
+                    if (to_light) which = (int)((double)sv.n_lights * g.next()); // HitableList::random, hitable.rs:74-77
+                    const uint32_t u1 = g.peek_u32(1), u2 = g.peek_u32(2);
+                    if (to_light) dir = light_random_fast(sv.lights[which], u1, u2, g, rec.p);
+                    else dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(u1, u2, g))) : iso_dir;
                     const F3 dirf = to_f3(dir);
                     const float len2 = dotf(dirf, dirf);
                     const F3 unit_dir = dirf * __builtin_amdgcn_rsqf(len2);

@@ -43,6 +43,11 @@ struct Rng {
         const uint32_t x = pcg32((uint32_t)key + n * 0x9E3779B9u);
         return pcg32(x ^ (uint32_t)(key >> 32));
     }
+    // the draw `ahead` places further on, without consuming anything
+    PT_DEV uint32_t peek_u32(uint32_t ahead) const {
+        const uint32_t x = pcg32((uint32_t)key + (n + ahead) * 0x9E3779B9u);
+        return pcg32(x ^ (uint32_t)(key >> 32));
+    }
     PT_DEV double next() { return (double)next_u32() * (1.0 / 4294967296.0); }
     // the same draw narrowed to f32 without ever rounding up to 1
     PT_DEV float nextf() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
@@ -729,29 +734,37 @@ PT_DEV F3 onbf_local(const OnbF &b, F3 a) {
               __builtin_fmaf(b.w.y, a.z, __builtin_fmaf(b.v.y, a.y, b.u.y * a.x)),
               __builtin_fmaf(b.w.z, a.z, __builtin_fmaf(b.v.z, a.y, b.u.z * a.x))};
 }
-PT_DEV F3 random_cosine_direction_f(Rng &g) { // src/material.rs:10-19
-    const float r1 = g.nextf();
-    const float r2 = g.nextf();
+// One light shape: Hitable::random (src/sphere.rs:96-101 with 16-25, src/rect.rs:135-144, default hitable.rs:33-35),
+// and the cosine lobe. Both take the raw bits u1, u2 of the NEXT two draws of `g` (Rng::peek_u32), which the caller has
+// computed once for every lane of the wave, whichever sampler a lane ends up in; a sampler that uses them consumes
+// them (g.n += 2), one that draws nothing (the default Hitable::random) leaves the stream where it is.
+PT_DEV float bits_to_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); } // Rng::nextf
+PT_DEV double bits_to_f64(uint32_t u) { return (double)u * (1.0 / 4294967296.0); }     // Rng::next
+PT_DEV F3 random_cosine_direction_f(uint32_t u1, uint32_t u2, Rng &g) { // src/material.rs:10-19
+    g.n += 2;
+    const float r1 = bits_to_f32(u1);
+    const float r2 = bits_to_f32(u2);
     const float z = __builtin_amdgcn_sqrtf(1.0f - r2);
     const float r2_sqrt = __builtin_amdgcn_sqrtf(r2);
     return f3(__builtin_amdgcn_cosf(r1) * r2_sqrt, __builtin_amdgcn_sinf(r1) * r2_sqrt, z);
 }
-// One light shape: Hitable::random (src/sphere.rs:96-101 with 16-25, src/rect.rs:135-144, default hitable.rs:33-35).
-PT_DEV D3 light_random_fast(const DevLight &l, Rng &g, D3 origin) {
+PT_DEV D3 light_random_fast(const DevLight &l, uint32_t u1, uint32_t u2, Rng &g, D3 origin) {
     if (l.kind == LIGHT_SPHERE) {
+        g.n += 2;
         const D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
         const float distance_sq = (float)squared_length(direction);
         const OnbF uvw = onbf_from_w(to_f3(direction));
-        const float r1 = g.nextf();
-        const float r2 = g.nextf();
+        const float r1 = bits_to_f32(u1);
+        const float r2 = bits_to_f32(u2);
         const float radius = (float)l.d[3];
         const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(1.0f - radius * radius * __builtin_amdgcn_rcpf(distance_sq)) - 1.0f);
         const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
         return to_d3(onbf_local(uvw, f3(__builtin_amdgcn_cosf(r1) * c, __builtin_amdgcn_sinf(r1) * c, z)));
     }
     if (l.kind == LIGHT_RECT) {
-        const double random_a = __builtin_fma(g.next(), l.d[1] - l.d[0], l.d[0]);
-        const double random_b = __builtin_fma(g.next(), l.d[3] - l.d[2], l.d[2]);
+        g.n += 2;
+        const double random_a = __builtin_fma(bits_to_f64(u1), l.d[1] - l.d[0], l.d[0]);
+        const double random_b = __builtin_fma(bits_to_f64(u2), l.d[3] - l.d[2], l.d[2]);
         const D3 p = l.axis == 0 ? d3(l.d[4], random_a, random_b)
                                  : (l.axis == 1 ? d3(random_a, l.d[4], random_b) : d3(random_a, random_b, l.d[4]));
         return p - origin;
