@@ -296,9 +296,6 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
         const uint32_t n = s_id * sh.shard_cap + ns; // first slot past this shard's entries
         if (FUSE) {
             extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
-#ifdef PT_EXPERIMENT_MISS
-            id = ht > 1e300 ? id : -1;
-#endif
         }
         if (i < n) {
             if (!FUSE) {
