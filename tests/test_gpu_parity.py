@@ -557,6 +557,37 @@ def test_tree_built_on_the_device(gpu_ctx, gpu_ctx_exact):
         gpu_ctx_exact.build_tree_on_device(2.0, 3.0)
 
 
+def test_tree_built_on_the_device_degenerate_layouts(gpu_ctx):
+    """The device build on layouts that stress its splits: 60 concentric spheres (every Morton code equal: middle
+    splits only), 60 spheres on a line parallel to an axis (the scene box has no extent on two axes), and a mix.
+    Hits through the device-built tree are those through the host-built one."""
+    rng = np.random.default_rng(31)
+    for layout in ("concentric", "line", "mixed"):
+        s = ptgpu.Scene()
+        mat = s.lambertian(s.texture_constant((0.5, 0.5, 0.5)))
+        nodes = []
+        for k in range(60):
+            if layout == "concentric" or (layout == "mixed" and k % 2):
+                nodes.append(s.sphere((10.0, 10.0, 10.0), 1.0 + 0.1 * k, mat))
+            else:
+                nodes.append(s.sphere((3.0 * k, 5.0, 5.0), 1.0, mat))
+        s.set_root(s.bvh(nodes, 0.0, 1.0))
+        s.set_lights([s.rect(0, 1, 0, 1, 50, 1, mat)])
+        s.camera = ptgpu.make_camera((10, 10, -60), (10, 10, 10), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+        n = 20_000
+        rays = np.zeros(n, dtype=ptgpu.RAY_DTYPE)
+        rays["origin"] = rng.uniform(-20, 200, size=(n, 3)) * np.array([1.0, 0.1, 0.1]) + np.array([0.0, 4.0, 4.0])
+        d = rng.normal(size=(n, 3))
+        rays["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        gpu_ctx.upload(s)
+        a = gpu_ctx.intersect(rays)
+        gpu_ctx.build_tree_on_device(0.0, 1.0)
+        b = gpu_ctx.intersect(rays)
+        assert (a["prim"] >= 0).mean() > 0.02, layout
+        assert np.array_equal(a["prim"], b["prim"]), layout
+        assert np.array_equal(a["t"], b["t"], equal_nan=True), layout
+
+
 def test_converged_images_agree_across_independent_seeds():
     """The estimator, not the random stream: the device image at 4096 spp from one seed and the oracle image at
     512 spp from another are independent estimates of the same picture. After a 4x4 box filter their difference
