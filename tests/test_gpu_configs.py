@@ -275,3 +275,32 @@ def test_exact_mode_pool_gives_the_same_image(name):
     assert int(st_b.last_pass_form) == ptgpu.PT_PASS_PATH_POOL
     assert np.array_equal(a, b, equal_nan=True)
     assert int(st_a.segments) == int(st_b.segments)
+
+
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (7, 3, 5), (65, 2, 3), (256, 1, 257)])
+def test_pool_on_tiny_and_ragged_passes(w, h, spp):
+    """Passes far smaller than one wave per compute unit, and passes whose last chunk of path ids is ragged: the pool
+    form and the launch-per-bounce form still give the same image, and every pixel is written."""
+    scene = ptgpu.Scene.named("cornell_box", w / h)
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            ctx = _ctx(max_paths_in_flight=1 << 12)
+            ctx.upload(scene)
+            ctx.render(w, h, spp, 50)
+            img, st = ctx.readback(), ctx.stats()
+            ctx.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return img, st
+
+    a, st_a = run({})
+    b, st_b = run({"PTGPU_PATH_POOL": "0", "PTGPU_PERSISTENT": "0"})
+    assert int(st_a.last_pass_form) == ptgpu.PT_PASS_PATH_POOL
+    assert int(st_b.last_pass_form) == ptgpu.PT_PASS_PER_BOUNCE_FUSED
+    assert int(st_a.paths) == int(st_b.paths) == w * h * spp
+    assert np.array_equal(a, b, equal_nan=True)
+    assert int(st_a.segments) == int(st_b.segments)
