@@ -325,6 +325,10 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
         error = "fewer than two primitives";
         return false;
     }
+    if (bld.prims.size() >= (size_t(1) << 28)) { // a leaf reference holds 28 bits of primitive index
+        error = "too many primitives";
+        return false;
+    }
     int32_t child, count;
     Box box;
     bld.build_child(0, (int)bld.prims.size(), 0, child, count, box);

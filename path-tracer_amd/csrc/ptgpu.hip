@@ -1067,6 +1067,7 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
     (void)hipSetDevice(ctx->device);
     const int32_t n = ctx->n_accel_prims;
     if (n < 2) return set_error(ctx, PT_ERR_UNSUPPORTED_SCENE, "fewer than two primitives");
+    if (n >= (1 << 28)) return set_error(ctx, PT_ERR_UNSUPPORTED_SCENE, "a leaf reference holds 28 bits of primitive index");
     // the scene's box for the new window: fit the current tree and read its root
     int rc = refit_levels(ctx, time0, time1);
     if (rc != PT_OK) return rc;
