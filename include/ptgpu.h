@@ -283,6 +283,18 @@ void *pt_stream(pt_ctx *ctx);
 int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double t_min, double t_max,
                         uint64_t medium_seed, int repeats, double *mean_ms_out);
 
+/* No counterpart in the reference (the crate never touches a device). The variant of pt_intersect for callers that
+ * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * d_rays (n pt_ray) and d_hits (n pt_hit) are DEVICE memory of the context's GPU, owned by the caller; the ray queue,
+ * the hit records and the fill count the extend kernels work on live in a fixed array inside the library's device
+ * image (about 6.8 MiB per GPU, held from the library's load to the end of the process), so the call performs no
+ * hipMalloc / hipFree. At most PT_INTERSECT_STATIC_MAX_RAYS rays per call (PT_ERR_TOO_LARGE beyond that). Same hits
+ * as pt_intersect, bit for bit. Synchronous. All contexts of one GPU share that GPU's array: calls that overlap in
+ * time on one GPU (from several contexts or threads) race; calls on different GPUs do not. */
+#define PT_INTERSECT_STATIC_MAX_RAYS 65536
+int pt_intersect_static(pt_ctx *ctx, const pt_ray *d_rays, size_t n, double t_min, double t_max,
+                        uint64_t medium_seed, pt_hit *d_hits);
+
 /* ------------------------------------------------------------------------ */
 /* Host-side scene construction (mirrors SceneBuilder / MaterialBuilder)     */
 /* ------------------------------------------------------------------------ */

@@ -228,7 +228,7 @@ EXPORTS = [
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
     "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
     "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_scene_build_device",
-    "pt_abi_version",
+    "pt_abi_version", "pt_intersect_static",
 ]
 
 _vp = C.c_void_p
@@ -295,6 +295,8 @@ _sig("pt_scene_accel_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p)
 _sig("pt_scene_refit", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_scene_build_device", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_abi_version", C.c_uint32)
+_sig("pt_intersect_static", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
+PT_INTERSECT_STATIC_MAX_RAYS = 65536
 
 
 class PtError(RuntimeError):
@@ -519,6 +521,14 @@ class Context:
             "pt_intersect_device",
         )
         return ms.value
+
+    def intersect_static(self, d_rays_ptr, n, d_hits_ptr, t_min=0.001, t_max=np.finfo(np.float64).max, medium_seed=0):
+        """pt_intersect on caller-owned DEVICE arrays of n pt_ray / n pt_hit, through the library's fixed scratch
+        array: no device allocation (pt_intersect_static)."""
+        self._check(
+            lib.pt_intersect_static(self._h, _vp(d_rays_ptr), n, float(t_min), float(t_max), C.c_uint64(medium_seed), _vp(d_hits_ptr)),
+            "pt_intersect_static",
+        )
 
     def tonemap_rgb8(self):
         """Reinhard + sqrt gamma + u8 of the context's image on the device, top row first (pt_tonemap_device)."""

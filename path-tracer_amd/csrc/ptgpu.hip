@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -38,6 +39,44 @@ namespace {
 #include "kernels_pool.h"
 #include "kernels_post.h"
 
+} // namespace
+
+// ================================================================================================================
+// Scratch of pt_intersect_static: the ray queue, the hit records and the queue's fill count of one batch of at most
+// PT_INTERSECT_STATIC_MAX_RAYS rays, in a device array that exists from the moment the library is loaded, so that the
+// entry point never allocates. Every GPU holds its own copy at its own address: `scratch` itself is only the host-side
+// handle of the symbol, and the address kernels are given comes from hipGetSymbolAddress on the device in question
+// (static_scratch_for, called by pt_create).
+// ================================================================================================================
+constexpr uint32_t kStaticMaxRays = PT_INTERSECT_STATIC_MAX_RAYS;
+static_assert(kStaticMaxRays % 256 == 0, "whole workgroup chunks");
+constexpr size_t kStaticQueueBytes = (size_t)(kStaticMaxRays / 64) * Queue::kTileBytes;
+constexpr size_t kStaticHitTOffset = kStaticQueueBytes;
+constexpr size_t kStaticHitIdOffset = kStaticHitTOffset + (size_t)kStaticMaxRays * sizeof(double);
+constexpr size_t kStaticCountsOffset = kStaticHitIdOffset + (size_t)kStaticMaxRays * sizeof(int32_t);
+constexpr size_t kStaticScratchBytes = kStaticCountsOffset + 256;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each GPU, once resolved
+
+// The device address of `scratch` on `device`, which must be the current device. Resolved once per device.
+hipError_t static_scratch_for(int device, unsigned char **out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (unsigned char *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 } // namespace
 
 // ================================================================================================================
@@ -129,6 +168,13 @@ struct pt_ctx {
     int32_t n_fused_ops = 0;
     std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
     uint32_t profile_n = 0;        // its path count
+
+    // Kept between calls and grown on demand, so that a loop of pt_intersect / pt_tonemap_device /
+    // pt_display_transform calls allocates once: [0] the ray batch, [1] the hit batch or the post kernels' output.
+    void *d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    hipEvent_t ev_batch[2] = {nullptr, nullptr}; // bracket the extend launches of a ray batch
+    unsigned char *d_static = nullptr;           // this GPU's copy of `scratch` (pt_intersect_static)
 };
 
 namespace {
@@ -242,6 +288,35 @@ int ensure_acc(pt_ctx *ctx, size_t pixels) {
     for (int k = 0; k < 3; ++k) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_acc[k], pixels * sizeof(double)));
     ctx->acc_capacity = pixels;
     return PT_OK;
+}
+
+int ensure_stage(pt_ctx *ctx, int k, size_t bytes) {
+    if (bytes <= ctx->stage_bytes[k]) return PT_OK;
+    if (ctx->d_stage[k]) (void)hipFree(ctx->d_stage[k]);
+    ctx->d_stage[k] = nullptr;
+    ctx->stage_bytes[k] = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_stage[k], bytes));
+    ctx->stage_bytes[k] = bytes;
+    return PT_OK;
+}
+
+// True when [p, p + bytes) lies inside one allocation of device memory on `device` (a kernel handed anything else
+// would fault the GPU instead of returning an error).
+bool device_range_ok(int device, const void *p, size_t bytes) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // a plain host pointer: not an error of the stream
+        return false;
+    }
+    if (attr.type != hipMemoryTypeDevice || attr.device != device) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const char *b = (const char *)base, *q = (const char *)p;
+    return q >= b && bytes <= size && (size_t)(q - b) <= size - bytes;
 }
 
 D3 hd3(const double p[3]) { return D3{p[0], p[1], p[2]}; }
@@ -606,6 +681,9 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(PT_ERR_HIP);
+    for (hipEvent_t &e : ctx->ev_batch)
+        if (hipEventCreate(&e) != hipSuccess) return bail(PT_ERR_HIP);
+    if (static_scratch_for(ctx->device, &ctx->d_static) != hipSuccess) return bail(PT_ERR_HIP);
     int rc = alloc_path_state(ctx);
     if (rc != PT_OK) return bail(rc);
     *out = ctx;
@@ -619,10 +697,13 @@ void pt_destroy(pt_ctx *ctx) {
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
-                    ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts};
+                    ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts,
+                    ctx->d_stage[0], ctx->d_stage[1]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto e : ctx->events) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_batch)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -811,6 +892,8 @@ int pt_image_bind(pt_ctx *ctx, void *device_rgba, uint32_t width, uint32_t heigh
         return PT_OK;
     }
     if (width == 0 || height == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "empty image");
+    if (!device_range_ok(ctx->device, device_rgba, (size_t)width * height * 4 * sizeof(float)))
+        return set_error(ctx, PT_ERR_INVALID_ARG, "device_rgba must be device memory of this context's GPU holding width*height*4 floats");
     if (ctx->d_image_owned) (void)hipFree(ctx->d_image_owned);
     ctx->d_image_owned = nullptr;
     ctx->image_external = true;
@@ -904,39 +987,45 @@ int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats) {
     return PT_OK;
 }
 
-static int intersect_common(pt_ctx *ctx, size_t n, double t_min, double t_max, uint64_t medium_seed, int repeats,
-                            double *mean_ms_out) {
+// Extend launches over the rays that sit in slots [0, n) of `q` (one shard: slot = ray index), hits left in
+// hit_t / hit_id. `counts` is the queue's fill count (one word on the device), written here. Nothing is allocated.
+static int extend_batch(pt_ctx *ctx, const Queue &q, uint32_t shard_cap, uint32_t *counts, double *hit_t, int32_t *hit_id,
+                        size_t n, double t_min, double t_max, uint64_t medium_seed, int repeats, double *mean_ms_out) {
     const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
-    const uint32_t n32 = (uint32_t)n;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_counts, &n32, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)counts, (int)(uint32_t)n, 1, ctx->stream));
     const int g = grid_for(ctx, n);
     ExtendArgs ea;
-    ea.counts = ctx->d_counts;
-    ea.sh = QueueShape{1u, 0u, ctx->capacity}; // one shard: slot == ray index
+    ea.counts = counts;
+    ea.sh = QueueShape{1u, 0u, shard_cap};
     ea.t_min = t_min;
     ea.t_max = t_max;
     ea.medium_seed = medium_seed;
     ea.key_mode = 1;
     ea.depth = 0;
-    ea.hit_t = ctx->d_hit_t;
-    ea.hit_id = ctx->d_hit_id;
+    ea.hit_t = hit_t;
+    ea.hit_id = hit_id;
     ea.counters = count ? ctx->d_trav : nullptr;
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    for (int r = 0; r < repeats; ++r) launch_extend(ctx, g, ctx->q[0], ea);
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (mean_ms_out) HIP_TRY(ctx, hipEventRecord(ctx->ev_batch[0], ctx->stream));
+    for (int r = 0; r < repeats; ++r) launch_extend(ctx, g, q, ea);
+    if (mean_ms_out) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_batch[1], ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_batch[0], ctx->ev_batch[1]));
+        *mean_ms_out = (double)ms / (double)repeats;
+    }
     HIP_TRY(ctx, hipGetLastError());
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (mean_ms_out) *mean_ms_out = (double)ms / (double)repeats;
-    ctx->stats.segments += 0;
     return PT_OK;
+}
+
+static void launch_store_hits(pt_ctx *ctx, const Queue &q, size_t n, const double *hit_t, const int32_t *hit_id, pt_hit *d_hits) {
+    const int g = grid_for(ctx, n);
+    if (ctx->exact)
+        hipLaunchKernelGGL(k_store_hits<true>, dim3(g), dim3(kBlock), 0, ctx->stream, q, (uint32_t)n, ctx->view, hit_t,
+                           hit_id, d_hits);
+    else
+        hipLaunchKernelGGL(k_store_hits<false>, dim3(g), dim3(kBlock), 0, ctx->stream, q, (uint32_t)n, ctx->view, hit_t,
+                           hit_id, d_hits);
 }
 
 int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double t_max, uint64_t medium_seed,
@@ -945,41 +1034,49 @@ int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double
     if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_intersect before pt_scene_upload");
     if (n == 0) return PT_OK;
     (void)hipSetDevice(ctx->device);
-    // batches larger than the queue capacity are processed in slices; the medium key uses the slice-local index
-    // offset by the slice start so results do not depend on the slicing
     if (n > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "ray batch larger than the paths-in-flight budget");
-    void *d_rays = nullptr, *d_hits = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_rays, n * sizeof(pt_ray)));
-    if (hipMalloc(&d_hits, n * sizeof(pt_hit)) != hipSuccess) {
-        (void)hipFree(d_rays);
-        return set_error(ctx, PT_ERR_OUT_OF_MEMORY, "hipMalloc hits");
-    }
-    int rc = PT_OK;
-    do {
-        if (hipMemcpyAsync(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-            rc = set_error(ctx, PT_ERR_HIP, "H2D rays");
-            break;
-        }
-        const int g = grid_for(ctx, n);
-        hipLaunchKernelGGL(k_load_rays, dim3(g), dim3(kBlock), 0, ctx->stream, (const pt_ray *)d_rays, (uint32_t)n,
-                           ctx->q[0]);
-        rc = intersect_common(ctx, n, t_min, t_max, medium_seed, 1, nullptr);
-        if (rc != PT_OK) break;
-        if (ctx->exact)
-            hipLaunchKernelGGL(k_store_hits<true>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], (uint32_t)n,
-                               ctx->view, ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)d_hits);
-        else
-            hipLaunchKernelGGL(k_store_hits<false>, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->q[0], (uint32_t)n,
-                               ctx->view, ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)d_hits);
-        if (hipMemcpyAsync(out, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            rc = set_error(ctx, PT_ERR_HIP, "D2H hits");
-            break;
-        }
-    } while (0);
-    (void)hipFree(d_rays);
-    (void)hipFree(d_hits);
-    return rc;
+    int rc = ensure_stage(ctx, 0, n * sizeof(pt_ray));
+    if (rc == PT_OK) rc = ensure_stage(ctx, 1, n * sizeof(pt_hit));
+    if (rc != PT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, (const pt_ray *)ctx->d_stage[0],
+                       (uint32_t)n, ctx->q[0]);
+    rc = extend_batch(ctx, ctx->q[0], ctx->capacity, ctx->d_counts, ctx->d_hit_t, ctx->d_hit_id, n, t_min, t_max,
+                      medium_seed, 1, nullptr);
+    if (rc != PT_OK) return rc;
+    launch_store_hits(ctx, ctx->q[0], n, ctx->d_hit_t, ctx->d_hit_id, (pt_hit *)ctx->d_stage[1]);
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_stage[1], n * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_intersect_static(pt_ctx *ctx, const pt_ray *d_rays, size_t n, double t_min, double t_max, uint64_t medium_seed,
+                        pt_hit *d_hits) {
+    if (!ctx || (n && (!d_rays || !d_hits))) return PT_ERR_INVALID_ARG;
+    if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_intersect_static before pt_scene_upload");
+    if (n == 0) return PT_OK;
+    if (n > kStaticMaxRays)
+        return set_error(ctx, PT_ERR_TOO_LARGE,
+                         "pt_intersect_static takes at most PT_INTERSECT_STATIC_MAX_RAYS (" +
+                             std::to_string(kStaticMaxRays) + ") rays per call, got " + std::to_string(n));
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->d_static) return set_error(ctx, PT_ERR_HIP, "the static scratch buffer was not resolved on this device");
+    if (!device_range_ok(ctx->device, d_rays, n * sizeof(pt_ray)) || !device_range_ok(ctx->device, d_hits, n * sizeof(pt_hit)))
+        return set_error(ctx, PT_ERR_INVALID_ARG, "d_rays / d_hits must be device memory of this context's GPU holding n entries");
+    // the device address resolved by pt_create, never the symbol's name
+    unsigned char *const base = ctx->d_static;
+    const Queue q{(char *)base};
+    double *const hit_t = (double *)(base + kStaticHitTOffset);
+    int32_t *const hit_id = (int32_t *)(base + kStaticHitIdOffset);
+    uint32_t *const counts = (uint32_t *)(base + kStaticCountsOffset);
+    hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, d_rays, (uint32_t)n, q);
+    const int rc = extend_batch(ctx, q, kStaticMaxRays, counts, hit_t, hit_id, n, t_min, t_max, medium_seed, 1, nullptr);
+    if (rc != PT_OK) return rc;
+    launch_store_hits(ctx, q, n, hit_t, hit_id, d_hits);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
 }
 
 int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double t_min, double t_max,
@@ -988,9 +1085,15 @@ int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double 
     if (!ctx->have_scene) return set_error(ctx, PT_ERR_NO_SCENE, "pt_intersect_device before pt_scene_upload");
     if (n > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "ray batch larger than the paths-in-flight budget");
     (void)hipSetDevice(ctx->device);
+    if (!device_range_ok(ctx->device, d_rays_soa, n * 7 * sizeof(double)))
+        return set_error(ctx, PT_ERR_INVALID_ARG, "d_rays_soa must be device memory of this context's GPU holding 7 n doubles");
     hipLaunchKernelGGL(k_load_rays_soa, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, d_rays_soa, (uint32_t)n,
                        ctx->q[0]);
-    return intersect_common(ctx, n, t_min, t_max, medium_seed, repeats, mean_ms_out);
+    double ms = 0.0;
+    const int rc = extend_batch(ctx, ctx->q[0], ctx->capacity, ctx->d_counts, ctx->d_hit_t, ctx->d_hit_id, n, t_min, t_max,
+                                medium_seed, repeats, &ms);
+    if (rc == PT_OK && mean_ms_out) *mean_ms_out = ms;
+    return rc;
 }
 
 int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes) {
@@ -999,15 +1102,13 @@ int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes) {
     const size_t need = (size_t)ctx->width * ctx->height * 3;
     if (n_bytes < need) return set_error(ctx, PT_ERR_INVALID_ARG, "rgb8_out too small");
     (void)hipSetDevice(ctx->device);
-    uint8_t *d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&d_out, need));
+    const int rc = ensure_stage(ctx, 1, need);
+    if (rc != PT_OK) return rc;
     const uint32_t n = ctx->width * ctx->height;
     hipLaunchKernelGGL(k_tonemap_rgb8, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image, ctx->width,
-                       ctx->height, d_out);
-    hipError_t e = hipMemcpyAsync(rgb8_out, d_out, need, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) return set_error(ctx, PT_ERR_HIP, hipGetErrorString(e));
+                       ctx->height, (uint8_t *)ctx->d_stage[1]);
+    HIP_TRY(ctx, hipMemcpyAsync(rgb8_out, ctx->d_stage[1], need, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 
@@ -1017,15 +1118,13 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     const size_t need = (size_t)ctx->width * ctx->height * 4;
     if (n_floats < need) return set_error(ctx, PT_ERR_INVALID_ARG, "rgba_out too small");
     (void)hipSetDevice(ctx->device);
-    float *d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&d_out, need * sizeof(float)));
+    const int rc = ensure_stage(ctx, 1, need * sizeof(float));
+    if (rc != PT_OK) return rc;
     const uint32_t n = ctx->width * ctx->height;
     hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image,
-                       ctx->width, ctx->height, exposure, d_out);
-    hipError_t e = hipMemcpyAsync(rgba_out, d_out, need * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) return set_error(ctx, PT_ERR_HIP, hipGetErrorString(e));
+                       ctx->width, ctx->height, exposure, (float *)ctx->d_stage[1]);
+    HIP_TRY(ctx, hipMemcpyAsync(rgba_out, ctx->d_stage[1], need * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 
