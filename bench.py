@@ -112,6 +112,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pt = importlib.import_module("path-tracer_amd")
+    pt.register_earthmap()  # texels of the image texture (tests/golden/make_earthmap.py)
     tiles = importlib.import_module("path-tracer_amd.tiles")
     W, H = args.width, args.height
     scene = pt.Scene.named(args.scene, W / H, seed=SEED, param=args.scene_param)

@@ -41,7 +41,8 @@ typedef enum pt_status {
     PT_ERR_NO_SCENE = -5,
     PT_ERR_NO_CAMERA = -6,
     PT_ERR_OUT_OF_MEMORY = -7,
-    PT_ERR_TOO_LARGE = -8
+    PT_ERR_TOO_LARGE = -8,
+    PT_ERR_MISSING_ASSET = -9 /* a named recipe needs an image that was not registered */
 } pt_status;
 
 /* ------------------------------------------------------------------------ */
@@ -305,6 +306,12 @@ typedef struct pt_scene pt_scene; /* owns the arrays a pt_scene_desc points into
  * `param` is recipe-specific (sphere count for "sphere_cloud", 1 = book semantics for "cornell_smoke"). */
 int pt_scene_build_named(const char *name, double aspect, uint64_t seed, int64_t param,
                          pt_scene **out, pt_camera *camera_out);
+/* Replaces the decode step of ImageTexture::new(EARTH_TEXTURE_BYTES) (src/texture.rs:84-98, src/lib.rs:767): the crate
+ * embeds assets/textures/earthmap.jpg and decodes it with the `image` crate; this library decodes nothing. The host
+ * decodes the file once and registers its RGB8 texels (rows top-down, as `to_rgb().into_vec()` yields them) under the
+ * file's name; "textured_sphere" and "final_book_two" use "earthmap.jpg" (1024 x 512) and return
+ * PT_ERR_MISSING_ASSET from pt_scene_build_named when it is not registered. The texels are copied. */
+int pt_asset_register_image(const char *name, const uint8_t *rgb8, int width, int height);
 void pt_scene_free(pt_scene *scene);
 int pt_scene_get_desc(const pt_scene *scene, pt_scene_desc *out);
 

@@ -33,6 +33,7 @@ PT_ERR_NO_SCENE = -5
 PT_ERR_NO_CAMERA = -6
 PT_ERR_OUT_OF_MEMORY = -7
 PT_ERR_TOO_LARGE = -8
+PT_ERR_MISSING_ASSET = -9
 
 PT_MODE_OFFLINE = 0
 PT_MODE_REALTIME = 1
@@ -228,7 +229,7 @@ EXPORTS = [
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
     "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
     "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_scene_build_device",
-    "pt_abi_version", "pt_intersect_static",
+    "pt_abi_version", "pt_intersect_static", "pt_asset_register_image",
 ]
 
 _vp = C.c_void_p
@@ -294,6 +295,7 @@ _sig("pt_session_frame", C.c_int, _vp, C.POINTER(UserInput), C.c_double, C.POINT
 _sig("pt_scene_accel_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p)
 _sig("pt_scene_refit", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_scene_build_device", C.c_int, _vp, C.c_double, C.c_double)
+_sig("pt_asset_register_image", C.c_int, C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int)
 _sig("pt_abi_version", C.c_uint32)
 _sig("pt_intersect_static", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
 PT_INTERSECT_STATIC_MAX_RAYS = 65536
@@ -319,6 +321,26 @@ def _check_id(rc, what):
     return rc
 
 
+EARTHMAP_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap_1024x512_rgb8.npz")
+
+
+def register_image(name, rgb8):
+    """Hands the decoded RGB8 texels (H x W x 3, rows top-down) of an image file to the library under the file's name
+    (pt_asset_register_image); the recipes "textured_sphere" and "final_book_two" need "earthmap.jpg"."""
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, c = a.shape
+    if c != 3:
+        raise ValueError("RGB8 texels expected")
+    rc = lib.pt_asset_register_image(name.encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
+    if rc != PT_OK:
+        raise PtError(rc, f"pt_asset_register_image({name})")
+
+
+def register_earthmap(path=None):
+    """Registers the committed decode of the reference's earthmap.jpg (tests/golden/make_earthmap.py wrote it)."""
+    register_image("earthmap.jpg", np.load(path or EARTHMAP_FIXTURE)["rgb8"])
+
+
 class Scene:
     """Host-side scene: a named recipe of the reference or one built node by node (SceneBuilder mirror)."""
 
@@ -335,6 +357,8 @@ class Scene:
         self._h = _vp()
         cam = Camera()
         rc = lib.pt_scene_build_named(name.encode(), float(aspect), C.c_uint64(seed), C.c_int64(param), C.byref(self._h), C.byref(cam))
+        if rc == PT_ERR_MISSING_ASSET:
+            raise PtError(rc, f"pt_scene_build_named({name}): the recipe needs earthmap.jpg; call register_earthmap() first")
         if rc != PT_OK:
             raise PtError(rc, f"pt_scene_build_named({name})")
         self.camera = cam
@@ -351,6 +375,7 @@ class Scene:
         rc = lib.pt_scene_get_desc(self._h, C.byref(d))
         if rc != PT_OK:
             raise PtError(rc, "pt_scene_get_desc")
+        d._owner = self  # the arrays the description points into live as long as the scene does
         return d
 
     # textures / materials

@@ -42,10 +42,19 @@ int pt_scene_build_named(const char *name, double aspect, uint64_t seed, int64_t
     }
     if (!ok) {
         delete s;
-        return PT_ERR_INVALID_ARG;
+        return error.rfind("missing asset", 0) == 0 ? PT_ERR_MISSING_ASSET : PT_ERR_INVALID_ARG;
     }
     *out = s;
     return PT_OK;
+}
+
+int pt_asset_register_image(const char *name, const uint8_t *rgb8, int width, int height) {
+    if (!name || !rgb8 || width <= 0 || height <= 0) return PT_ERR_INVALID_ARG;
+    try {
+        return register_image_asset(name, rgb8, width, height) ? PT_OK : PT_ERR_INVALID_ARG;
+    } catch (const std::bad_alloc &) {
+        return PT_ERR_OUT_OF_MEMORY;
+    }
 }
 
 void pt_scene_free(pt_scene *scene) { delete scene; }

@@ -23,13 +23,26 @@ int main(int argc, char **argv) {
         if (a.rfind("-height=", 0) == 0) ny = (uint32_t)std::atoi(a.c_str() + 8);
         if (a.rfind("-scene=", 0) == 0) scene_name = a.substr(7);
         if (a.rfind("-out=", 0) == 0) out = a.substr(5);
+        // decoded texels of assets/textures/earthmap.jpg: 1024 x 512 RGB8, rows top-down (src/lib.rs:767)
+        if (a.rfind("-earthmap=", 0) == 0) {
+            std::vector<uint8_t> texels((size_t)1024 * 512 * 3);
+            FILE *fp = std::fopen(a.c_str() + 10, "rb");
+            const size_t got = fp ? std::fread(texels.data(), 1, texels.size(), fp) : 0;
+            if (fp) std::fclose(fp);
+            if (got != texels.size() || pt_asset_register_image("earthmap.jpg", texels.data(), 1024, 512) != PT_OK) {
+                std::fprintf(stderr, "%s: expected %zu bytes of RGB8 texels\n", a.c_str() + 10, texels.size());
+                return 1;
+            }
+        }
     }
     std::printf("realtime: %d max_depth: %d spp: %u\n", config.realtime ? 1 : 0, config.max_depth, config.spp);
 
     pt_scene *scene = nullptr;
     pt_camera cam;
-    if (pt_scene_build_named(scene_name.c_str(), (double)nx / (double)ny, 0x5EED0001ull, 0, &scene, &cam) != PT_OK) {
-        std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str());
+    const int built = pt_scene_build_named(scene_name.c_str(), (double)nx / (double)ny, 0x5EED0001ull, 0, &scene, &cam);
+    if (built != PT_OK) {
+        std::fprintf(stderr, built == PT_ERR_MISSING_ASSET ? "scene %s needs -earthmap=FILE (RGB8 texels of earthmap.jpg)\n"
+                                                           : "unknown scene %s\n", scene_name.c_str());
         return 1;
     }
     pt_config cfg{};

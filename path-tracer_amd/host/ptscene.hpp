@@ -204,6 +204,8 @@ struct BuiltScene {
     Scene *scene = nullptr;
     pt_camera camera{};
 };
+// Decoded RGB8 texels of an image file a scene recipe refers to (rows top-down as decoded), kept for the process.
+bool register_image_asset(const std::string &name, const uint8_t *rgb8, int width, int height);
 bool build_named_scene(const std::string &name, double aspect, uint64_t seed, int64_t param, Scene &scene,
                        pt_camera &camera, std::string &error);
 

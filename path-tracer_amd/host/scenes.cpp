@@ -1,14 +1,30 @@
 // Scene recipes of the reference (src/lib.rs:674-1077), written against the builder mirror, plus the synthetic
 // one-million-sphere cloud used for deep-BVH stress. Every random number the reference takes from thread_rng
-// comes from the scene's seeded stream here, in the reference's call order.
+// comes from the scene's seeded stream here, in the reference's call order. The recipes are constant tables: they
+// follow the reference's functions statement by statement, local names included, so that each literal can be checked
+// against the line it comes from.
 #include "ptscene.hpp"
 
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace ptgpu {
 
 namespace {
+
+struct ImageAsset {
+    std::vector<uint8_t> rgb8;
+    int width = 0, height = 0;
+};
+std::mutex g_assets_mutex;
+std::map<std::string, ImageAsset> g_assets;
+struct MissingAsset {
+    std::string name;
+};
+bool build_named_scene_impl(const std::string &name, double aspect, int64_t param, Scene &s, pt_camera &camera,
+                            std::string &error);
 
 pt_camera make_camera(Vec3 lookfrom, Vec3 lookat, double vfov, double aspect, double aperture, double focus) {
     Camera cam(lookfrom, lookat, Vec3(0.0, 1.0, 0.0), vfov, aspect, aperture, focus, 0.0, 1.0);
@@ -93,32 +109,15 @@ void two_perlin_spheres(Scene &s) {
     s.set_root(s.bvh_from_list(list, 0.0, 1.0));
 }
 
-// A 1024x512 RGB8 stand-in for assets/textures/earthmap.jpg (the JPEG cannot be decoded without the
-// image crate): smooth "continents" so that nearest-texel lookups vary across the sphere.
-std::vector<uint8_t> synthetic_earth(int w, int h) {
-    std::vector<uint8_t> px((size_t)w * h * 3);
-    for (int j = 0; j < h; ++j)
-        for (int i = 0; i < w; ++i) {
-            double u = (double)i / w, v = (double)j / h;
-            double land = std::sin(12.566370614359172 * u) * std::cos(9.42477796076938 * v) +
-                          0.5 * std::sin(43.982297150257104 * u + 3.0 * v);
-            uint8_t *p = &px[((size_t)j * w + i) * 3];
-            if (land > 0.2) {
-                p[0] = (uint8_t)(60 + 120 * v);
-                p[1] = (uint8_t)(140 - 60 * v);
-                p[2] = 50;
-            } else {
-                p[0] = 20;
-                p[1] = (uint8_t)(60 + 40 * u);
-                p[2] = (uint8_t)(150 + 80 * v);
-            }
-        }
-    return px;
-}
-
+// ImageTexture::new(EARTH_TEXTURE_BYTES) (src/texture.rs:84-98, src/lib.rs:767): the reference embeds
+// assets/textures/earthmap.jpg and decodes it with the `image` crate when the scene is built. This library decodes
+// nothing: the host registers the decoded RGB8 texels under the asset's file name (pt_asset_register_image) before it
+// builds a recipe that uses them. There is no stand-in: a recipe whose asset is missing fails.
 Texture earth_texture(Scene &s) {
-    std::vector<uint8_t> px = synthetic_earth(1024, 512);
-    return s.image_texture(px.data(), 1024, 512);
+    std::lock_guard<std::mutex> lock(g_assets_mutex);
+    auto it = g_assets.find("earthmap.jpg");
+    if (it == g_assets.end()) throw MissingAsset{"earthmap.jpg"};
+    return s.image_texture(it->second.rgb8.data(), it->second.width, it->second.height);
 }
 
 // lib.rs:777-782
@@ -292,6 +291,28 @@ pt_camera sphere_cloud(Scene &s, double aspect, int64_t n) {
 bool build_named_scene(const std::string &name, double aspect, uint64_t seed, int64_t param, Scene &s,
                        pt_camera &camera, std::string &error) {
     (void)seed;
+    try {
+        return build_named_scene_impl(name, aspect, param, s, camera, error);
+    } catch (const MissingAsset &m) {
+        error = "missing asset: " + m.name + " (register its RGB8 texels with pt_asset_register_image first)";
+        return false;
+    }
+}
+
+bool register_image_asset(const std::string &name, const uint8_t *rgb8, int width, int height) {
+    if (name.empty() || !rgb8 || width <= 0 || height <= 0) return false;
+    ImageAsset a;
+    a.rgb8.assign(rgb8, rgb8 + (size_t)width * height * 3);
+    a.width = width;
+    a.height = height;
+    std::lock_guard<std::mutex> lock(g_assets_mutex);
+    g_assets[name] = std::move(a);
+    return true;
+}
+
+namespace {
+bool build_named_scene_impl(const std::string &name, double aspect, int64_t param, Scene &s, pt_camera &camera,
+                            std::string &error) {
     // Cameras the reference keeps in comments for the non-Cornell scenes (lib.rs:308-323).
     pt_camera book_cam = make_camera(Vec3(26.0, 2.0, 3.0), Vec3(0.0, 0.0, 0.0), 20.0, aspect, 0.0, 10.0);
     if (name == "two_spheres") {
@@ -341,5 +362,6 @@ bool build_named_scene(const std::string &name, double aspect, uint64_t seed, in
     }
     return true;
 }
+} // namespace
 
 } // namespace ptgpu

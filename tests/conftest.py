@@ -14,6 +14,7 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
 # The package directory has a hyphen in its name, so it is imported by string and aliased.
 ptgpu = importlib.import_module("path-tracer_amd")
 sys.modules.setdefault("ptgpu", ptgpu)
+ptgpu.register_earthmap()  # the image texture of textured_sphere / final_book_two (tests/golden/make_earthmap.py)
 
 
 def pytest_configure(config):

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 pt = importlib.import_module("path-tracer_amd")
+pt.register_earthmap()  # texels of the image texture (tests/golden/make_earthmap.py)
 import oracle_binding as ob
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000

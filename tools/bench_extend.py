@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 pt = importlib.import_module("path-tracer_amd")
+pt.register_earthmap()  # texels of the image texture (tests/golden/make_earthmap.py)
 import oracle_binding as ob
 
 scenes = sys.argv[1:] or ["cornell_box", "random_scene", "final_book_two", "sphere_cloud"]

@@ -11,6 +11,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pt = importlib.import_module("path-tracer_amd")
+pt.register_earthmap()  # texels of the image texture (tests/golden/make_earthmap.py)
 
 scene_name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box"
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

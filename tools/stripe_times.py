@@ -4,6 +4,7 @@ import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pt = importlib.import_module("path-tracer_amd")
+pt.register_earthmap()  # texels of the image texture (tests/golden/make_earthmap.py)
 W = H = 1024
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 64
