@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -173,19 +173,40 @@ typedef struct pt_hit {
 
 typedef struct pt_ctx pt_ctx;
 
+/* How the library runs its passes. Every field: 0 = the library's default. None of them changes a pixel; they exist
+ * for A/B measurements and for tests that compare the forms. (The environment variable PTGPU_TUNING,
+ * "field=value,field=value", overrides fields by name in an unmodified host.) */
+typedef struct pt_tuning {
+    uint32_t pass_form;            /* pt_pass_form to use where the scene allows it; 0 = the library chooses */
+    uint32_t pool_refill;          /* path pool: free path slots (1..64) at which a wave takes new camera samples */
+    uint32_t pool_chunk;           /* pool kernels: path ids a wave takes from the pass's counter at a time (64..2^20) */
+    uint32_t pool_grid;            /* pool kernels: workgroups per resident slot (1..256) */
+    uint32_t tree_refill, tree_inner, tree_shade; /* tree pool thresholds in lanes (1..64): refill at / stay on inner
+                                                     nodes while / shade when this many lanes ... */
+    uint32_t tree_trav_plus1;      /* ... or at most this many minus one (1..65) still traverse */
+    uint32_t accel_form;           /* extend stage over the SAH tree: 1 = a ray per thread, 2 = refilled lane pool */
+    uint32_t accel_refill, accel_inner, accel_grid; /* lane pool thresholds (1..64, 1..65) and workgroups per slot (1..8) */
+    uint32_t shards;               /* shards of the render queues: 1, 2, 4 .. 64 */
+    uint32_t scan_max_ops_plus1;   /* op streams up to this length minus one are walked wave-uniformly */
+    uint32_t list_max_leaves_plus1;/* scenes up to this many primitives minus one are walked as a box-free list */
+    uint32_t profile_period;       /* with PT_CFG_PROFILE_STAGES: every n-th pass is bracketed with events */
+} pt_tuning;
+
 typedef struct pt_config {
-    uint32_t struct_size;
+    uint32_t struct_size;        /* sizeof(pt_config); the ABI-1 size (without `tuning`) is accepted too */
     int32_t device;              /* HIP device ordinal */
     uint64_t seed;               /* master seed of the counter-based RNG */
     uint32_t max_paths_in_flight;/* paths per wavefront pass; 0 = library default */
     uint32_t flags;              /* PT_CFG_* */
+    pt_tuning tuning;
 } pt_config;
 
 #define PT_CFG_PROFILE_STAGES 1u /* bracket every kernel launch of sampled passes with HIP events */
 #define PT_CFG_COUNT_TRAVERSAL 2u /* count node visits / primitive tests in the extend kernel */
-#define PT_CFG_EXACT 4u /* IEEE division everywhere and no fused multiply-add: bit-faithful to an f64 CPU evaluation
-                           of the reference's expressions; the default replaces quotients by refined reciprocals,
-                           fuses a*b+c and samples directions with f32 sin/cos (a few ulp per operation) */
+#define PT_CFG_EXACT 4u /* IEEE division and square roots everywhere and no fused multiply-add: bit-faithful to an f64
+                           CPU evaluation of the reference's expressions. The default is f64 as well, with quotients
+                           and roots by refined hardware reciprocals, a*b+c fused, and sin / cos of 2 pi r from a
+                           quadrant reduction and polynomials (a few ulp per operation) */
 
 typedef enum pt_render_mode {
     PT_MODE_OFFLINE = 0,    /* overwrite rgb with the mean of spp samples (src/trace.rs:178-181) */
@@ -220,10 +241,8 @@ typedef struct pt_stats {
     uint64_t prim_tests;       /* primitives tested  (needs PT_CFG_COUNT_TRAVERSAL) */
     uint64_t nan_pixels;       /* pixels whose last written colour has a NaN channel */
     uint64_t launches_raygen, launches_extend, launches_shade, launches_resolve;
-    double ms_raygen, ms_extend, ms_shade, ms_resolve; /* summed HIP-event time of profiled launches; when an offline
-                                                        * pass's bounce 0 makes its own rays (launches_raygen == 0) that
-                                                        * launch is timed under ms_raygen and its segments are not in
-                                                        * profiled_segments */
+    double ms_raygen, ms_extend, ms_shade, ms_resolve; /* summed HIP-event time of profiled launches (a one-launch
+                                                        * pass form is timed under ms_shade) */
     uint64_t profiled_segments;/* segments processed by the profiled extend/shade launches */
     uint64_t profiled_paths;   /* paths processed by the profiled raygen/resolve launches */
     uint64_t profiled_passes;  /* profiled raygen (= resolve) launches */
@@ -235,8 +254,7 @@ typedef struct pt_stats {
 enum pt_pass_form {
     PT_PASS_NONE = 0,
     PT_PASS_PER_BOUNCE = 1,       /* ray generation, then an extend and a shade launch per bounce */
-    PT_PASS_PER_BOUNCE_FUSED = 2, /* primitive-list scenes: one trace+shade launch per bounce */
-    PT_PASS_PERSISTENT = 3,       /* primitive-list scenes: ray generation + one launch over queue tiles */
+    PT_PASS_PERSISTENT = 3,       /* primitive-list scenes: ray generation + one trace-and-shade launch over queue tiles */
     PT_PASS_PATH_POOL = 4,        /* primitive-list scenes, offline: one launch, paths stay in registers */
     PT_PASS_TREE_POOL = 5         /* tree scenes, offline: one launch, traversal and shading inside the wave */
 };

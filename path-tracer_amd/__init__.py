@@ -154,6 +154,15 @@ class FrameInfo(C.Structure):
     ]
 
 
+TUNING_FIELDS = ("pass_form", "pool_refill", "pool_chunk", "pool_grid", "tree_refill", "tree_inner", "tree_shade",
+                 "tree_trav_plus1", "accel_form", "accel_refill", "accel_inner", "accel_grid", "shards",
+                 "scan_max_ops_plus1", "list_max_leaves_plus1", "profile_period")
+
+
+class Tuning(C.Structure):
+    _fields_ = [(name, C.c_uint32) for name in TUNING_FIELDS]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -161,6 +170,7 @@ class Config(C.Structure):
         ("seed", C.c_uint64),
         ("max_paths_in_flight", C.c_uint32),
         ("flags", C.c_uint32),
+        ("tuning", Tuning),
     ]
 
 
@@ -183,7 +193,7 @@ class RenderArgs(C.Structure):
     ]
 
 
-PT_PASS_NONE, PT_PASS_PER_BOUNCE, PT_PASS_PER_BOUNCE_FUSED, PT_PASS_PERSISTENT, PT_PASS_PATH_POOL, PT_PASS_TREE_POOL = range(6)
+PT_PASS_NONE, PT_PASS_PER_BOUNCE, PT_PASS_PERSISTENT, PT_PASS_PATH_POOL, PT_PASS_TREE_POOL = 0, 1, 3, 4, 5
 
 
 class Stats(C.Structure):
@@ -463,8 +473,9 @@ def make_camera(origin, look_at, vup=(0, 1, 0), vfov=40.0, aspect=1.0, aperture=
 class Context:
     """One GPU's render state (pt_ctx)."""
 
-    def __init__(self, device=0, seed=0x5EED0001, max_paths_in_flight=0, flags=0):
-        cfg = Config(C.sizeof(Config), device, seed, max_paths_in_flight, flags)
+    def __init__(self, device=0, seed=0x5EED0001, max_paths_in_flight=0, flags=0, **tuning):
+        """tuning: fields of pt_tuning by name (pass_form=PT_PASS_PER_BOUNCE, pool_chunk=64, ...)."""
+        cfg = Config(C.sizeof(Config), device, seed, max_paths_in_flight, flags, Tuning(**tuning))
         self._h = _vp()
         rc = lib.pt_create(C.byref(cfg), C.byref(self._h))
         if rc != PT_OK:

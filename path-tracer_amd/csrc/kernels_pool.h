@@ -30,7 +30,7 @@ struct PoolLds {
 #endif
 // X: exact mode. The walk is the wave-uniform scan of the reference's own threaded tree (every box test, the
 // reference's order), the arithmetic is M<true>'s; sv.ops is then the full stream, not the fused list.
-template <bool NEED_UV, int FUSE, bool X = false>
+template <int TEX, int FUSE, bool X = false>
 __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
                                                                       uint32_t max_depth, double *lx, double *ly,
                                                                       double *lz, uint32_t *counts, uint32_t flags,
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
         if (has) {
             const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
             D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
-            const bool alive = shade_vertex<X, NEED_UV, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
+            const bool alive = shade_vertex<X, TEX, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht,
                                                                         id, depth, max_depth, flags, lx, ly, lz, no, nd,
                                                                         nbeta, &c);
             // the per-path sum of the other forms: the first vertex is stored, later ones are added unless zero
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
 #ifndef PT_TREE_UV_WAVES
 #define PT_TREE_UV_WAVES 2 // waves per SIMD of the textured variants: their shading is the largest code here (4: 638, 3: 640, 2: 730 Mpaths/s on the final scene)
 #endif
-template <bool NEED_UV, bool MEDIA>
-__global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
+template <int TEX, bool MEDIA>
+__global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock, NEED_UV ? PT_TREE_UV_WAVES : PT_SHADE_WAVES
             if (ready) {
                 const int32_t li = best < 0 ? 0 : (best & 0x0fffffff);
                 D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
-                const bool alive = shade_vertex<false, NEED_UV, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
+                const bool alive = shade_vertex<false, TEX, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
                                                                             closest, best, depth, max_depth, flags, lx, ly,
                                                                             lz, no, nd, nbeta, &c);
                 if (depth == 0) sum = c; // the per-path sum of the other forms

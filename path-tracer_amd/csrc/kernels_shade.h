@@ -1,4 +1,4 @@
-// One path vertex (the body of `color`, src/trace.rs:198-234) and the queue-based pass forms built on it: a launch per bounce, bounce 0 with its own rays, persistent waves.
+// One path vertex (the body of `color`, src/trace.rs:198-234) and the queue-based pass forms built on it: a shade launch per bounce, and persistent waves that trace and shade.
 // Part of ptgpu.hip (included inside its unnamed namespace, in this order); not a standalone header.
 
 // ------------------------------------------------------------------------------------------------------------
@@ -20,12 +20,10 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
 // miss. `lf` is the hit primitive's leaf record (fields are fetched where they are used; any record when id < 0).
 // Adds the vertex's radiance to the path's accumulator and, if the path goes on, returns true with the next ray,
 // throughput and RNG draw count.
-// FIRST: the vertex is the path's first one and nothing has initialised the path's accumulator: the vertex's
-// radiance (every branch adds at most once) is stored, zero included, instead of added.
-// RETURN: the vertex's radiance is handed back in `vertex_radiance` and nothing is written (the caller keeps the
-// path's sum).
-enum RadianceMode { RAD_ADD = 0, RAD_FIRST = 1, RAD_RETURN = 2 };
-template <bool X, bool NEED_UV, int FIRST = RAD_ADD>
+// RAD_RETURN: the vertex's radiance (every branch adds at most once) is handed back in `vertex_radiance` and nothing
+// is written (the caller keeps the path's sum).
+enum RadianceMode { RAD_ADD = 0, RAD_RETURN = 2 };
+template <bool X, int TEX, int FIRST = RAD_ADD>
 __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, D3 beta,
                                              uint64_t pkey, uint32_t pid, uint32_t &rn, double ht, int32_t id,
                                              uint32_t depth, uint32_t max_depth, uint32_t flags, double *lx, double *ly,
@@ -41,8 +39,8 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
         add_radiance(lx, ly, lz, pid, beta * 0.0);
     } else {
         Rng g{pkey, rn};
-        const HitRec rec = finalize_hit<X, NEED_UV>(sv, lf, o, d, time, ht, (id >> 28) & 7);
-        const D3 emissive = emitted(sv, lf, d, rec);
+        const HitRec rec = finalize_hit<X, TEX>(sv, lf, o, d, time, ht, (id >> 28) & 7);
+        const D3 emissive = emitted<TEX>(sv, lf, d, rec);
         bool done = true, dead = false;
         if (depth < max_depth) {
             if (lf.mat_kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
@@ -84,83 +82,51 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     if (book) iso_dir = sample;
                 }
                 const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
-                const D3 albedo = leaf_texture(sv, lf, rec);
+                const D3 albedo = leaf_texture<TEX>(sv, lf, rec);
                 add_radiance(lx, ly, lz, pid, beta * emissive);
-#ifndef PT_F64_WEIGHTS
-#define PT_F64_WEIGHTS 0
-#endif
-                if constexpr (X || PT_F64_WEIGHTS) {
-                    Onb uvw;
-                    if (lambert) uvw = onb_from_w<X>(rec.n);
-                    // MixturePDF::generate, src/material.rs:427-433
-                    D3 dir;
-                    if (g.next() < 0.5) dir = lights_random<X>(sv, g, rec.p);
-                    else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(g)) : iso_dir;
-                    // MixturePDF::value, src/material.rs:424-426
-                    const D3 unit_dir = M<X>::unit_vector(dir);
-                    double own = iso_pdf;
-                    if (lambert) { // CosinePDF::value, src/material.rs:375-382
-                        double cosine = M<X>::dot(unit_dir, uvw.w);
-                        own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
-                    }
-                    const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir) + 0.5 * own;
-                    double spdf = iso_pdf;
-                    if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
-                        double cosine = M<X>::dot(rec.n, unit_dir);
-                        spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
-                    }
-                    // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
-                    nbeta = M<X>::divs(beta * (albedo * spdf), pdf_val);
-                    nd = dir;
-                    if constexpr (!X) { // fast mode: see the f32 form below
-                        const bool below = lambert && spdf == 0.0;
-                        if (below) nbeta = d3(0.0, 0.0, 0.0);
-                        dead = below && !sv.has_isotropic;
-                    }
-                } else {
-                    // same estimator with the weights in f32 (see "f32 radiometry" in pt_device.h)
-                    const F3 nf = to_f3(rec.n);
-                    OnbF uvw;
-                    if (lambert) uvw = onbf_from_w(nf);
-                    D3 dir;
-                    // MixturePDF::generate (src/material.rs:427-433). Every sampler a lane can end up in takes its
-                    // next two draws (or none): their bits are made once, by all lanes together, before the lanes
-                    // part ways, instead of once per branch by the lanes of that branch.
-                    const bool to_light = g.next() < 0.5;
-                    int which = 0;
-                    if (to_light) which = (int)((double)sv.n_lights * g.next()); // HitableList::random, hitable.rs:74-77
-                    const uint32_t u1 = g.peek_u32(1), u2 = g.peek_u32(2);
-                    if (to_light) dir = light_random_fast(sv.lights[which], u1, u2, g, rec.p);
-                    else dir = lambert ? to_d3(onbf_local(uvw, random_cosine_direction_f(u1, u2, g))) : iso_dir;
-                    const F3 dirf = to_f3(dir);
-                    const float len2 = dotf(dirf, dirf);
-                    const F3 unit_dir = dirf * __builtin_amdgcn_rsqf(len2);
-                    float own = (float)iso_pdf, spdf = (float)iso_pdf;
-                    if (lambert) {
-                        const float cw = dotf(unit_dir, uvw.w);
-                        own = cw > 0.0f ? cw * 0.31830988618379067154f : 0.0f;
-                        const float cn = dotf(nf, unit_dir);
-                        spdf = cn < 0.0f ? 0.0f : cn * 0.31830988618379067154f;
-                    }
-                    const float weight = __builtin_amdgcn_rcpf((float)sv.n_lights);
-                    float lsum = 0.0f;
-                    for (int k = 0; k < sv.n_lights; ++k)
-                        lsum += weight * light_pdf_value_fast(sv.lights[k], rec.p, dirf, len2);
-                    const float pdf_val = 0.5f * lsum + 0.5f * own;
-                    const float inv_pdf = __builtin_amdgcn_rcpf(pdf_val);
-                    // Isotropic: 0 * x / 0 must stay NaN (src/trace.rs:217-220): rcp(0) = inf, 0 * inf = NaN.
-                    // Lambertian: a direction below the surface has scattering_pdf 0 and its sample weighs
-                    // nothing. In f64 the mixture pdf is then still positive (the direction came from a
-                    // light); in f32 a grazing light sample can also miss its light by rounding, which
-                    // would turn 0 / pdf into 0 / 0, so the weight is pinned to the 0 the reference gets.
-                    const bool below = lambert && spdf == 0.0f; // a NaN spdf is not "below": it propagates
-                    const float wr = below ? 0.0f : ((float)albedo.x * spdf) * inv_pdf;
-                    const float wg = below ? 0.0f : ((float)albedo.y * spdf) * inv_pdf;
-                    const float wb = below ? 0.0f : ((float)albedo.z * spdf) * inv_pdf;
-                    nbeta = beta * d3((double)wr, (double)wg, (double)wb);
-                    nd = dir;
-                    // A path whose throughput is exactly 0 can only add 0 * (finite radiance) from here on;
-                    // without Isotropic materials nothing downstream turns that into NaN, so it stops here.
+                Onb uvw;
+                if (lambert) uvw = onb_from_w<X>(rec.n);
+                // MixturePDF::generate (src/material.rs:427-433), then HitableList::random (src/hitable.rs:74-77) or
+                // the material's own pdf. Every sampler a lane can end up in takes its next two draws (or none):
+                // their bits are made once, by all lanes together, before the lanes part ways.
+                const bool to_light = g.next() < 0.5;
+                int which = 0;
+                if (to_light) which = (int)((double)sv.n_lights * g.next());
+                const uint32_t u1 = g.peek_u32(1), u2 = g.peek_u32(2);
+                D3 dir;
+                if (to_light) dir = light_random<X>(sv.lights[which], u1, u2, g, rec.p);
+                else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(u1, u2, g)) : iso_dir;
+                // MixturePDF::value, src/material.rs:424-426
+                double len2 = 0.0, inv_len = 0.0;
+                D3 unit_dir;
+                if constexpr (X) unit_dir = M<X>::unit_vector(dir);
+                else {
+                    len2 = M<X>::squared_length(dir);
+                    inv_len = weight_rsqrt(len2);
+                    unit_dir = dir * inv_len;
+                }
+                double own = iso_pdf;
+                if (lambert) { // CosinePDF::value, src/material.rs:375-382
+                    double cosine = M<X>::dot(unit_dir, uvw.w);
+                    own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
+                }
+                const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir, len2, inv_len) + 0.5 * own;
+                double spdf = iso_pdf;
+                if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
+                    double cosine = M<X>::dot(rec.n, unit_dir);
+                    spdf = cosine < 0.0 ? 0.0 : cosine * kFrac1Pi;
+                }
+                // colour = albedo * spdf * color(next) / pdf_val + emissive (src/trace.rs:217-221)
+                nbeta = W<X>::divs(beta * (albedo * spdf), pdf_val);
+                nd = dir;
+                if constexpr (!X) {
+                    // A Lambertian direction below the surface has scattering_pdf 0: the reference goes on with a
+                    // throughput of 0 * x / pdf = 0 (the mixture pdf is positive there: the direction came from a
+                    // light). Such a path can only add 0 * (finite radiance) from here on; without Isotropic
+                    // materials nothing downstream turns that into NaN, so fast mode stops it. The weight is pinned
+                    // to the 0 the reference gets, also where a reciprocal's rounding would make pdf_val 0.
+                    const bool below = lambert && spdf == 0.0; // a NaN spdf is not "below": it propagates
+                    if (below) nbeta = d3(0.0, 0.0, 0.0);
                     dead = below && !sv.has_isotropic;
                 }
                 no = rec.p;
@@ -171,19 +137,13 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
         alive = !done && !dead;
         rn = g.n;
     }
-    if constexpr (FIRST == RAD_FIRST) {
-        lx[pid] = first.x;
-        ly[pid] = first.y;
-        lz[pid] = first.z;
-    }
     if constexpr (FIRST == RAD_RETURN) *vertex_radiance = first;
     return alive;
 }
 
-// FUSE = 0: hits come from the extend kernel through hit_t / hit_id.
-// FUSE = 1 / 2: the scene is a short box-free op list (2: with media); the ray is traced right here before it is
-// shaded, so the extend launch, its re-read of the ray and the hit round trip through HBM disappear. The op list is
-// passed in sv.ops / sv.n_traversal_ops.
+// The kernels that trace AND shade (FUSE = 1, or 2 with media): the scene is a short box-free op list, walked right
+// before the vertex is shaded, so no extend launch, no re-read of the ray and no hit round trip through HBM. The op
+// list is passed in sv.ops / sv.n_traversal_ops.
 // A leaf record padded to 200 B: with a stride of 50 dwords the same field of different leaves spreads over 16 LDS
 // banks instead of 2.
 struct LdsLeaf {
@@ -194,12 +154,7 @@ constexpr int kLdsLeaves = 32; // the fused kernels keep the whole leaf table in
 
 // LDS of one workgroup. Kept as ONE object: with a second __shared__ object beside a buffer that direct-to-LDS loads
 // fill, the compiler waits for those loads before every LDS read.
-template <int FUSE> struct ShadeLds {
-    uint32_t cnt[kWavesPerBlock + 1];
-    LdsLeaf leaves[1];
-    unsigned char tile[1][16];
-};
-template <> struct ShadeLds<1> {
+struct ShadeLds {
     alignas(16) unsigned char tile[kWavesPerBlock][Queue::kTileBytes]; // each wave's next queue tile
     LdsLeaf leaves[kLdsLeaves];
     uint32_t cnt[kWavesPerBlock + 1];
@@ -234,92 +189,44 @@ __device__ __forceinline__ void prefetch_tile(const Queue &q, uint32_t tile, uns
 // Every vector memory operation of the wave, the tile copy included, has completed.
 __device__ __forceinline__ void tile_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool X, bool NEED_UV, int FUSE>
+// Shade stage on its own: hits come from the extend kernel through hit_t / hit_id (scenes traced through a tree in
+// realtime frames and in exact mode). Survivors are compacted into the output queue: wave64 ballot + popcount, wave
+// totals in LDS, one atomic per workgroup and shard.
+template <bool X, int TEX>
 __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue qi, Queue qo, QueueShape sh, const uint32_t *n_in,
                                                   uint32_t *n_out, SceneView sv, const double *hit_t, const int32_t *hit_id,
                                                   double *lx, double *ly, double *lz,
                                                   uint32_t depth, uint32_t max_depth, uint32_t flags) {
-    __shared__ ShadeLds<(FUSE != 0) ? 1 : 0> S;
-    uint32_t *lds = S.cnt;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    __shared__ uint32_t lds[kWavesPerBlock + 1];
     const uint32_t n_virtual = ((max_shard_count(n_in, sh.shards) + kBlock - 1) / kBlock) << sh.shift;
-    // first queue tile of virtual chunk v that this wave handles
-    auto tile_of = [&](uint32_t v) -> uint32_t {
-        return (((v & (sh.shards - 1)) * sh.shard_cap + (v >> sh.shift) * kBlock) >> 6) + wave;
-    };
-    if constexpr (FUSE != 0) {
-        if (blockIdx.x < n_virtual) prefetch_tile(qi, tile_of(blockIdx.x), S.tile[wave], lane);
-        // Shading gathers ~100 B of its leaf per lane through a chain of dependent loads (kind -> geometry ->
-        // material); from LDS each link costs tens of cycles instead of an L1/L2 round trip.
-        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
-        const double *src = (const double *)sv.leaves;
-        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
-            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
-        tile_wait();
-        __syncthreads();
-    }
     for (uint32_t v = blockIdx.x; v < n_virtual; v += gridDim.x) {
         const uint32_t s_id = v & (sh.shards - 1);
         const uint32_t ns = shard_count(n_in, s_id);
         const uint32_t row0 = (v >> sh.shift) * kBlock;
+        if (row0 >= ns) continue; // uniform for the workgroup
         bool alive = false;
         D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
         double time = 0.0;
         uint32_t pid = 0, rn = 0;
-        D3 o, d, beta;
-        double ht = 0.0;
-        int32_t id = -1;
         uint64_t pkey = 0;
-        if constexpr (FUSE != 0) {
-            // This wave's tile was requested one iteration ago (or before the loop) and has had a whole trace + shade
-            // to arrive. Every field moves into registers, then the buffer is handed to the request for the tile of
-            // the next iteration, which the work below hides. Lanes past the shard's fill read stale entries: they
-            // are traced (whole waves walk the op list together) and dropped.
-            const unsigned char *e = S.tile[wave] + lane * 8u;
-            o = d3(*(const double *)(e + 0 * 512), *(const double *)(e + 1 * 512), *(const double *)(e + 2 * 512));
-            d = d3(*(const double *)(e + 3 * 512), *(const double *)(e + 4 * 512), *(const double *)(e + 5 * 512));
-            time = *(const double *)(e + 6 * 512);
-            beta = d3(*(const double *)(e + 7 * 512), *(const double *)(e + 8 * 512), *(const double *)(e + 9 * 512));
-            pkey = *(const uint64_t *)(e + 10 * 512);
-            pid = *(const uint32_t *)(S.tile[wave] + 5632 + lane * 4u);
-            rn = *(const uint32_t *)(S.tile[wave] + 5888 + lane * 4u);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads are done before the buffer is refilled
-            const uint32_t vn = v + gridDim.x;
-            if (vn < n_virtual) prefetch_tile(qi, tile_of(vn), S.tile[wave], lane);
-        }
-        if (row0 >= ns) { // uniform for the workgroup
-            if constexpr (FUSE != 0) tile_wait();
-            continue;
-        }
         const uint32_t local = row0 + threadIdx.x;
         const uint32_t i = s_id * sh.shard_cap + local;
         const uint32_t n = s_id * sh.shard_cap + ns; // first slot past this shard's entries
-        if (FUSE) {
-            extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id);
-        }
         if (i < n) {
-            if (!FUSE) {
-                o = d3(qi.ox(i), qi.oy(i), qi.oz(i));
-                d = d3(qi.dx(i), qi.dy(i), qi.dz(i));
-                time = qi.tm(i);
-                pid = qi.pid(i);
-                id = hit_id[i];
-                ht = hit_t[i];
-                beta = d3(qi.bx(i), qi.by(i), qi.bz(i));
-                rn = qi.rn(i);
-            }
-            if (!FUSE) pkey = qi.key(i);
-            const DevLeaf *lfp;
+            const D3 o = d3(qi.ox(i), qi.oy(i), qi.oz(i));
+            const D3 d = d3(qi.dx(i), qi.dy(i), qi.dz(i));
+            time = qi.tm(i);
+            pid = qi.pid(i);
+            const int32_t id = hit_id[i];
+            const double ht = hit_t[i];
+            const D3 beta = d3(qi.bx(i), qi.by(i), qi.bz(i));
+            rn = qi.rn(i);
+            pkey = qi.key(i);
             const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
-            if constexpr (FUSE != 0) lfp = &S.leaves[li].l;
-            else lfp = &sv.leaves[li];
-            alive = shade_vertex<X, NEED_UV>(sv, *lfp, o, d, time, beta, pkey, pid, rn, ht, id, depth, max_depth, flags,
-                                             lx, ly, lz, no, nd, nbeta);
+            alive = shade_vertex<X, TEX>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn, ht, id, depth, max_depth, flags,
+                                         lx, ly, lz, no, nd, nbeta);
         }
         const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], lds);
-        // The next tile was requested a whole trace + shade ago; retiring it here, ahead of this iteration's stores,
-        // costs next to nothing, while a wait at the top of the loop would also sit out those stores.
-        if constexpr (FUSE != 0) tile_wait();
         if (alive) {
             qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
             qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
@@ -333,83 +240,6 @@ __global__ __launch_bounds__(kBlock, X ? 1 : PT_SHADE_WAVES) void k_shade(Queue 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Bounce 0 of an offline pass of a fused scene: the camera sample is generated, traced and shaded in one go, so the
-// first queue (96 B per path written by raygen and read back by the first shade launch) never exists. Same chunk
-// to shard mapping as k_raygen, same camera arithmetic, same draws.
-// ------------------------------------------------------------------------------------------------------------
-template <bool NEED_UV, int FUSE>
-__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_first_bounce(Queue qo, QueueShape sh, uint32_t *counts,
-                                                                         SceneView sv, CameraDev cam, PassParams pp,
-                                                                         double *lx, double *ly, double *lz,
-                                                                         uint32_t flags) {
-    __shared__ ShadeLds<1> S;
-    {
-        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
-        const double *src = (const double *)sv.leaves;
-        for (int k = threadIdx.x; k < sv.n_leaves * kWords; k += kBlock)
-            ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
-        __syncthreads();
-    }
-    uint32_t *n_out = counts + kShards;
-    const uint32_t n = pp.cpix * pp.s_count;
-    const uint32_t n_chunks = (n + kBlock - 1) / kBlock;
-    for (uint32_t j = blockIdx.x; j < n_chunks; j += gridDim.x) {
-        const uint32_t s_id = j & (sh.shards - 1);
-        const uint32_t pid = j * kBlock + threadIdx.x;
-        const bool valid = pid < n;
-        const uint32_t pc = valid ? pid : 0u; // lanes past the end trace path 0 again and are dropped
-        const uint32_t p = pc % pp.cpix, s = pc / pp.cpix;
-        const uint32_t i = pp.cx0 + p % pp.cw;
-        const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
-        const uint64_t pixel = (uint64_t)jy * pp.width + i;
-        Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
-        double random = g.next(); // src/trace.rs:153-156
-        const double u = ((double)i + random) / (double)pp.width;
-        random = g.next();
-        const double v = ((double)jy + random) / (double)pp.height;
-        const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
-        const D3 offset = cam.u * rd.x + cam.v * rd.y;
-        const double time = cam.time0 + g.next() * (cam.time1 - cam.time0);
-        const D3 d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
-        const D3 o = cam.origin + offset;
-        const D3 beta = d3(1.0, 1.0, 1.0);
-        uint32_t rn = g.n;
-        double ht;
-        int32_t id;
-        extend_list<FUSE == 2>(sv, sv.ops, o, d, time, g.key, 0u, 0.001, kF64Max, ht, id);
-        bool alive = false;
-        D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
-        if (valid) {
-            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
-            alive = shade_vertex<false, NEED_UV, RAD_FIRST>(sv, S.leaves[li].l, o, d, time, beta, g.key, pid, rn, ht, id, 0u,
-                                                       pp.max_depth, flags, lx, ly, lz, no, nd, nbeta);
-        }
-        const uint32_t slot = s_id * sh.shard_cap + compact_slot(alive, &n_out[s_id], S.cnt);
-        if (alive) {
-            qo.ox(slot) = no.x; qo.oy(slot) = no.y; qo.oz(slot) = no.z;
-            qo.dx(slot) = nd.x; qo.dy(slot) = nd.y; qo.dz(slot) = nd.z;
-            qo.tm(slot) = time;
-            qo.bx(slot) = nbeta.x; qo.by(slot) = nbeta.y; qo.bz(slot) = nbeta.z;
-            qo.pid(slot) = pid;
-            qo.rn(slot) = rn;
-            qo.key(slot) = g.key;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < sh.shards) {
-        // segments of bounce 0, per shard, as k_raygen counts them (statistics only: nothing reads a first queue)
-        const uint32_t k = threadIdx.x;
-        uint32_t fill = 0;
-        if (n_chunks > k) {
-            const uint32_t mine = (n_chunks - k + sh.shards - 1) >> sh.shift;
-            fill = mine * kBlock;
-            const uint32_t last = k + (mine - 1) * sh.shards;
-            if (last == n_chunks - 1) fill -= n_chunks * kBlock - n;
-        }
-        counts[k] = fill;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // Persistent form of the fused pipeline: ONE launch traces a whole pass. The pass's paths are dealt to the resident
 // waves in contiguous runs of queue tiles; a wave then carries its own paths through every bounce, compacting the
 // survivors into the same run of tiles of the other queue. A wave shares nothing with any other wave: no atomics on
@@ -417,12 +247,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_first_bounce(Queue q
 // partly filled tile per wave and bounce, a few per cent of the tile steps. Which wave carries a path has no effect
 // on the path (its RNG is keyed by pixel and sample), so images are bit-identical to the launch-per-bounce form.
 // ------------------------------------------------------------------------------------------------------------
-template <bool NEED_UV, int FUSE>
+template <int TEX, int FUSE>
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_trace_persistent(Queue qa, Queue qb, uint32_t *counts,
                                                                              SceneView sv, double *lx, double *ly,
                                                                              double *lz, uint32_t max_depth,
                                                                              uint32_t flags) {
-    __shared__ ShadeLds<1> S;
+    __shared__ ShadeLds S;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     {
         constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
@@ -464,7 +294,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_trace_persistent(Que
             D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0);
             if (t * 64u + lane < n) { // lanes past the fill traced a stale entry; they are dropped here
                 const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
-                alive = shade_vertex<false, NEED_UV>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht, id, depth,
+                alive = shade_vertex<false, TEX>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht, id, depth,
                                                      max_depth, flags, lx, ly, lz, no, nd, nbeta);
             }
             const unsigned long long ballot = __ballot(alive);

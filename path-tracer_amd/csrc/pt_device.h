@@ -49,8 +49,6 @@ struct Rng {
         return pcg32(x ^ (uint32_t)(key >> 32));
     }
     PT_DEV double next() { return (double)next_u32() * (1.0 / 4294967296.0); }
-    // the same draw narrowed to f32 without ever rounding up to 1
-    PT_DEV float nextf() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
 };
 PT_DEV uint64_t path_key(uint64_t seed, uint64_t frame, uint64_t pixel, uint64_t sample) {
     uint64_t k = mix64(seed ^ (0xA0761D6478BD642FULL * (frame + 1)));
@@ -91,10 +89,11 @@ PT_DEV D3 unit_vector(D3 a) { return a / length(a); }
 // ---------------------------------------------------------- math policy --
 // X = true  : "exact" mode. Every quotient is a true IEEE division and nothing is fused, so results match an
 //             f64 CPU evaluation of the reference's expressions bit for bit (up to libm differences).
-// X = false : "fast" mode (default). Quotients become a multiply by a Newton-refined v_rcp_f64 (about 1 ulp),
-//             sums of products use FMA, and the two trigonometric calls of the direction samplers run on the
-//             f32 transcendental unit. Geometry stays f64; results differ from exact mode by a few ulp per
-//             operation, far inside the 1e-4 relative bar on hit distances.
+// X = false : "fast" mode (default). Still f64 from end to end: quotients become a multiply by a Newton-refined
+//             v_rcp_f64 (about 1 ulp), square roots a Newton-refined v_rsq_f64, sums of products use FMA, and
+//             sin / cos of 2 pi r come from a quadrant reduction and two polynomials instead of libm's general
+//             routines. Results differ from exact mode by a few ulp per operation, far inside the 1e-4 relative bar
+//             on hit distances.
 PT_DEV double fast_rcp(double y) {
     const double r0 = __builtin_amdgcn_rcp(y); // ~2^-26 relative error
     double e = __builtin_fma(-y, r0, 1.0);
@@ -113,11 +112,60 @@ PT_DEV double fast_rsqrt(double x) {
     y = __builtin_fma(y * 0.5, e, y);
     return y;
 }
+// The same with ONE refinement step: relative error about 2^-50 (reciprocal) and 2^-44 (square roots). Used where the
+// value only WEIGHTS a path (pdf values, cosines, sampled local directions): seven to nine decimal digits more than
+// an f32 evaluation, at two thirds of the instructions of the fully refined forms. Geometry (hit distances, hit
+// points, ray directions that are traced) never uses these.
+PT_DEV double weight_rcp(double y) {
+    const double r0 = __builtin_amdgcn_rcp(y);
+    const double e = __builtin_fma(-y, r0, 1.0);
+    const double r = __builtin_fma(e, r0, r0);
+    return (__builtin_isinf(r0) || r0 == 0.0) ? r0 : r;
+}
+PT_DEV double weight_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * 0.5, e, y);
+}
+PT_DEV double weight_sqrt(double x) {
+    const double r = x * weight_rsqrt(x);
+    return x == 0.0 ? 0.0 : r;
+}
 // sqrt(x) for finite x >= 0 (x = 0 gives 0, not 0 * inf)
 PT_DEV double fast_sqrt(double x) {
     const double r = x * fast_rsqrt(x);
     return x == 0.0 ? 0.0 : r;
 }
+// sin(2 pi r), cos(2 pi r) for r in [0, 1], f64, about 1 ulp: r is split exactly into a quarter turn count q and a
+// remainder f in [-1/8, 1/8]; x = 2 pi f lies in [-pi/4, pi/4], where the two minimax polynomials below (the kernels
+// every libm uses on that interval) are accurate to below one ulp; the quadrant then swaps and negates. No table, no
+// branch, about thirty FMA-class instructions for both values.
+PT_DEV void fast_sincos_2pi(double r, double &sn, double &cs) {
+    const double q = __builtin_rint(r * 4.0);
+    const double f = __builtin_fma(q, -0.25, r); // exact
+    const double x = f * 6.283185307179586476925286766559;
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double s0 = __builtin_fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double c0 = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int k = (int)q; // 0 .. 4
+    const bool swap = (k & 1) != 0;
+    const double a = swap ? c0 : s0, b = swap ? s0 : c0;
+    sn = (k & 2) ? -a : a;
+    cs = ((k + 1) & 2) ? -b : b;
+}
+
 template <bool X> struct M {
     static PT_DEV double rcp(double y) {
         if constexpr (X) return 1.0 / y;
@@ -169,9 +217,30 @@ template <bool X> struct M {
             cs = cos(phi);
             sn = sin(phi);
         } else {
-            const float rf = (float)r; // v_sin_f32 / v_cos_f32 take their argument in revolutions
-            sn = (double)__builtin_amdgcn_sinf(rf);
-            cs = (double)__builtin_amdgcn_cosf(rf);
+            fast_sincos_2pi(r, sn, cs);
+        }
+    }
+};
+
+// Arithmetic of the quantities that only weight a path. Exact mode: the same IEEE operations as M<true>.
+template <bool X> struct W {
+    static PT_DEV double rcp(double y) {
+        if constexpr (X) return 1.0 / y;
+        else return weight_rcp(y);
+    }
+    static PT_DEV double div(double a, double b) {
+        if constexpr (X) return a / b;
+        else return a * weight_rcp(b);
+    }
+    static PT_DEV double sqrt_(double v) {
+        if constexpr (X) return sqrt(v);
+        else return weight_sqrt(v);
+    }
+    static PT_DEV D3 divs(D3 a, double s) {
+        if constexpr (X) return D3{a.x / s, a.y / s, a.z / s};
+        else {
+            const double r = weight_rcp(s);
+            return D3{a.x * r, a.y * r, a.z * r};
         }
     }
 };
@@ -459,7 +528,8 @@ PT_DEV void get_sphere_uv(D3 p, double &u, double &v) { // src/sphere.rs:8-14
 // Rebuilds the HitRecord of the closest hit from (world ray, t, leaf, sub): the leaf's full chain takes the
 // ray to the primitive's space with the same sequence of operations the traversal used, the record is built
 // there as the primitive's hit() does, then carried back out through the wrappers in reverse.
-template <bool X, bool NEED_UV>
+// TEX: what the scene's textures need (see texture_value); surface (u, v) are only computed for TEX == 2.
+template <bool X, int TEX>
 PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, double t, int sub) {
     apply_chain<X>(sv.xforms, lf.full_start, lf.full_count, o, d);
     HitRec r;
@@ -473,14 +543,14 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, d
     r.p = point;
     if (lf.kind == OP_SPHERE) {
         D3 c = d3(g[0], g[1], g[2]);
-        if (NEED_UV) {
+        if (TEX == 2) {
             if (sub == 0) get_sphere_uv(M<X>::divs(c - point, g[3]), r.u, r.v); // sphere.rs:56
             else get_sphere_uv(c - point, r.u, r.v);                               // sphere.rs:69
         }
         r.n = M<X>::divs(point - c, g[3]);
     } else if (lf.kind == OP_MSPHERE) {
         D3 c = moving_center<X>(g, lf.e, time);
-        if (NEED_UV) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
+        if (TEX == 2) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
         r.n = M<X>::divs(point - c, g[3]);
     } else if (lf.kind == OP_RECT || lf.kind == OP_BOXPRIM) {
         double amin, amax, bmin, bmax, c;
@@ -492,7 +562,7 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, d
             box_face(g, sub, amin, amax, bmin, bmax, c, axis);
             r.prim = lf.prim[sub];
         }
-        if (NEED_UV) {
+        if (TEX == 2) {
             double a, b;
             if (axis == 0) { a = M<X>::mad(t, d.y, o.y); b = M<X>::mad(t, d.z, o.z); }
             else if (axis == 1) { a = M<X>::mad(t, d.x, o.x); b = M<X>::mad(t, d.z, o.z); }
@@ -554,7 +624,14 @@ PT_DEV double clamp_ref(double a, double lo, double hi) { // src/math/mod.rs:22-
     return b;
 }
 // Texture::value (src/texture.rs:24-28, 47-56, 70-75, 101-114). Checker children are resolved iteratively.
-PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) {
+// TEX is the scene's texture level, a property of the uploaded scene that the kernels are specialised on:
+//   0  every material's texture is a constant colour (already copied into the leaf records: nothing to evaluate);
+//   1  checker / noise textures occur (functions of the hit point);
+//   2  image textures occur too (functions of the surface u, v).
+// The Perlin evaluation alone is several thousand instructions and some forty registers; a kernel for a scene without
+// it must not carry it.
+template <int TEX> PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) {
+    if constexpr (TEX == 0) return d3(0.0, 0.0, 0.0);
     const pt_texture *t = &sv.textures[tex];
     for (int guard = 0; guard < 16 && t->kind == PT_T_CHECKER; ++guard) {
         double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
@@ -566,7 +643,7 @@ PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) 
         double g = 1.0 * 0.5 * (1.0 + sin(noise));
         return d3(g, g, g);
     }
-    if (t->kind == PT_T_IMAGE) {
+    if (TEX == 2 && t->kind == PT_T_IMAGE) {
         double wf = (double)t->width, hf = (double)t->height;
         double ci = clamp_ref(u * wf, 0.0, wf - 1.0);
         double cj = clamp_ref(v * hf - 0.001, 0.0, hf - 1.0);
@@ -585,21 +662,40 @@ struct Onb { // src/onb.rs:18-37
     D3 u, v, w;
 };
 template <bool X> PT_DEV Onb onb_from_w(D3 n) {
-    D3 w = M<X>::unit_vector(n);
-    D3 a = fabs(w.x) > 0.9 ? d3(0.0, 1.0, 0.0) : d3(1.0, 0.0, 0.0);
-    D3 v = M<X>::unit_vector(cross(w, a));
-    D3 u = cross(w, v);
-    return Onb{u, v, w};
+    if constexpr (X) {
+        D3 w = M<X>::unit_vector(n);
+        D3 a = fabs(w.x) > 0.9 ? d3(0.0, 1.0, 0.0) : d3(1.0, 0.0, 0.0);
+        D3 v = M<X>::unit_vector(cross(w, a));
+        D3 u = cross(w, v);
+        return Onb{u, v, w};
+    } else {
+        // the same basis with the products by the zeros and ones of `a` written out: w x (0,1,0) = (-w.z, 0, w.x),
+        // w x (1,0,0) = (0, w.z, -w.y)
+        const D3 w = n * weight_rsqrt(M<X>::squared_length(n));
+        const bool big = fabs(w.x) > 0.9;
+        const double p = big ? w.x : w.y;
+        const double r = weight_rsqrt(__builtin_fma(w.z, w.z, p * p));
+        const D3 v = big ? d3(-w.z * r, 0.0, w.x * r) : d3(0.0, w.z * r, -w.y * r);
+        const D3 u = cross(w, v);
+        return Onb{u, v, w};
+    }
 }
 PT_DEV D3 onb_local(const Onb &b, D3 a) { return b.u * a.x + b.v * a.y + b.w * a.z; }
 
-template <bool X> PT_DEV D3 random_cosine_direction(Rng &g) { // src/material.rs:10-19
-    double r1 = g.next();
-    double r2 = g.next();
-    double z = M<X>::sqrt_(1.0 - r2);
+// The direction samplers below take the raw bits u1, u2 of the NEXT two draws of `g` (Rng::peek_u32), which the
+// caller computes once for every lane of the wave, whichever sampler a lane ends up in: the integer hashing then runs
+// once with all lanes active instead of once per branch with the lanes of that branch. A sampler that uses the draws
+// consumes them (g.n += 2); one that draws nothing (the default Hitable::random) leaves the stream where it is. The
+// values are those of two g.next() calls.
+PT_DEV double bits_to_f64(uint32_t u) { return (double)u * (1.0 / 4294967296.0); } // Rng::next
+template <bool X> PT_DEV D3 random_cosine_direction(uint32_t u1, uint32_t u2, Rng &g) { // src/material.rs:10-19
+    g.n += 2;
+    const double r1 = bits_to_f64(u1);
+    const double r2 = bits_to_f64(u2);
+    double z = W<X>::sqrt_(1.0 - r2);
     double sn, cs;
     M<X>::sincos_2pi(r1, sn, cs);
-    double r2_sqrt = M<X>::sqrt_(r2);
+    double r2_sqrt = W<X>::sqrt_(r2);
     double x = cs * r2_sqrt;
     double y = sn * r2_sqrt;
     return d3(x, y, z);
@@ -626,13 +722,13 @@ PT_DEV D3 random_in_unit_disk(Rng &g) { // src/camera.rs:221-228
     }
     return nv;
 }
-template <bool X> PT_DEV D3 random_to_sphere(Rng &g, double radius, double distance_squared) { // src/sphere.rs:16-25
-    double r1 = g.next();
-    double r2 = g.next();
-    double z = 1.0 + r2 * (M<X>::sqrt_(1.0 - M<X>::div(radius * radius, distance_squared)) - 1.0);
+template <bool X> PT_DEV D3 random_to_sphere(uint32_t u1, uint32_t u2, double radius, double distance_squared) { // src/sphere.rs:16-25
+    const double r1 = bits_to_f64(u1);
+    const double r2 = bits_to_f64(u2);
+    double z = 1.0 + r2 * (W<X>::sqrt_(1.0 - W<X>::div(radius * radius, distance_squared)) - 1.0);
     double sn, cs;
     M<X>::sincos_2pi(r1, sn, cs);
-    double c = M<X>::sqrt_(1.0 - z * z);
+    double c = W<X>::sqrt_(1.0 - z * z);
     double x = cs * c;
     double y = sn * c;
     return d3(x, y, z);
@@ -640,181 +736,85 @@ template <bool X> PT_DEV D3 random_to_sphere(Rng &g, double radius, double dista
 
 // ---------------------------------------------------------------- lights --
 // Hitable::pdf_value of one light shape (src/sphere.rs:87-95, src/rect.rs:124-133, default src/hitable.rs:30-32).
-template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3 direction) {
+// `len2` = |direction|^2 and `inv_len` = 1 / |direction| come from the caller, which needs them anyway (fast mode; exact
+// mode recomputes them the way the reference does).
+template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3 direction, double len2, double inv_len) {
     if (l.kind == LIGHT_SPHERE) {
-        double t;
-        int which;
         D3 c = d3(l.d[0], l.d[1], l.d[2]);
-        if (sphere_t<X>(c, l.d[3], origin, direction, 0.001, kF64Max, t, which)) {
-            double cos_theta_max = M<X>::sqrt_(1.0 - M<X>::div(l.d[3] * l.d[3], M<X>::squared_length(c - origin)));
+        bool hit;
+        if constexpr (X) {
+            double t;
+            int which;
+            hit = sphere_t<X>(c, l.d[3], origin, direction, 0.001, kF64Max, t, which);
+        } else {
+            // Sphere::hit accepts a root in (0.001, MAX); the larger root passes whenever the smaller does, so the ray
+            // hits iff disc > 0 and (-b + sqrt(disc)) / a > 0.001, i.e. sqrt(disc) > y with y = 0.001 a + b: true for
+            // y < 0, else disc > y^2. No square root, no quotient.
+            const D3 oc = origin - c;
+            const double b = M<X>::dot(oc, direction);
+            const double cc = __builtin_fma(-l.d[3], l.d[3], M<X>::dot(oc, oc));
+            const double disc = __builtin_fma(-len2, cc, b * b);
+            const double y = __builtin_fma(0.001, len2, b);
+            hit = (disc > 0.0) & ((y < 0.0) | (disc > y * y));
+        }
+        if (hit) {
+            double cos_theta_max = W<X>::sqrt_(1.0 - W<X>::div(l.d[3] * l.d[3], M<X>::squared_length(c - origin)));
             double solid_angle = 2.0 * kPi * (1.0 - cos_theta_max);
-            return M<X>::rcp(solid_angle);
+            return W<X>::rcp(solid_angle);
         }
         return 0.0;
     }
     if (l.kind == LIGHT_RECT) {
         double t;
         D3 inv = d3(0.0, 0.0, 0.0);
+        const double dk = l.axis == 0 ? direction.x : (l.axis == 1 ? direction.y : direction.z);
         if constexpr (!X) {
-            const double dk = l.axis == 0 ? direction.x : (l.axis == 1 ? direction.y : direction.z);
             const double r = fast_rcp(dk);
             inv = d3(r, r, r);
         }
         if (rect_t<X>(l.d[0], l.d[1], l.d[2], l.d[3], l.d[4], l.axis, origin, direction, inv, 0.001, kF64Max, t)) {
             double area = (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]);
-            double v_sq_length = M<X>::squared_length(direction);
-            double distance_sq = t * t * v_sq_length;
-            D3 normal = l.axis == 0 ? d3(1.0, 0.0, 0.0) : (l.axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
-            double cosine = fabs(M<X>::div(dot(direction, normal), M<X>::sqrt_(v_sq_length)));
-            return M<X>::div(distance_sq, cosine * area);
+            if constexpr (X) {
+                double v_sq_length = M<X>::squared_length(direction);
+                double distance_sq = t * t * v_sq_length;
+                D3 normal = l.axis == 0 ? d3(1.0, 0.0, 0.0) : (l.axis == 1 ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
+                double cosine = fabs(dot(direction, normal) / sqrt(v_sq_length));
+                return distance_sq / (cosine * area);
+            } else {
+                const double distance_sq = t * t * len2;
+                const double cosine = fabs(dk * inv_len);
+                return distance_sq * weight_rcp(cosine * area);
+            }
         }
         return 0.0;
     }
     return 0.0;
 }
 // Hitable::random of one light shape (src/sphere.rs:96-101, src/rect.rs:135-144, default src/hitable.rs:33-35).
-template <bool X> PT_DEV D3 light_random(const DevLight &l, Rng &g, D3 origin) {
+template <bool X> PT_DEV D3 light_random(const DevLight &l, uint32_t u1, uint32_t u2, Rng &g, D3 origin) {
     if (l.kind == LIGHT_SPHERE) {
+        g.n += 2;
         D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
         double distance_sq = M<X>::squared_length(direction);
         Onb uvw = onb_from_w<X>(direction);
-        return onb_local(uvw, random_to_sphere<X>(g, l.d[3], distance_sq));
+        return onb_local(uvw, random_to_sphere<X>(u1, u2, l.d[3], distance_sq));
     }
     if (l.kind == LIGHT_RECT) {
-        double random_a = l.d[0] + g.next() * (l.d[1] - l.d[0]);
-        double random_b = l.d[2] + g.next() * (l.d[3] - l.d[2]);
+        g.n += 2;
+        double random_a = l.d[0] + bits_to_f64(u1) * (l.d[1] - l.d[0]);
+        double random_b = l.d[2] + bits_to_f64(u2) * (l.d[3] - l.d[2]);
         D3 p = l.axis == 0 ? d3(l.d[4], random_a, random_b)
                            : (l.axis == 1 ? d3(random_a, l.d[4], random_b) : d3(random_a, random_b, l.d[4]));
         return p - origin;
     }
     return d3(1.0, 0.0, 0.0);
 }
-// HitableList::pdf_value / random over the light list (src/hitable.rs:66-77).
-template <bool X> PT_DEV double lights_pdf_value(const SceneView &sv, D3 origin, D3 direction) {
+// HitableList::pdf_value over the light list (src/hitable.rs:66-73).
+template <bool X> PT_DEV double lights_pdf_value(const SceneView &sv, D3 origin, D3 direction, double len2, double inv_len) {
     double weight = 1.0 / (double)sv.n_lights;
     double sum = 0.0;
-    for (int k = 0; k < sv.n_lights; ++k) sum += weight * light_pdf_value<X>(sv.lights[k], origin, direction);
+    for (int k = 0; k < sv.n_lights; ++k) sum += weight * light_pdf_value<X>(sv.lights[k], origin, direction, len2, inv_len);
     return sum;
-}
-template <bool X> PT_DEV D3 lights_random(const SceneView &sv, Rng &g, D3 origin) {
-    double x = (double)sv.n_lights * g.next();
-    int index = (int)x;
-    return light_random<X>(sv.lights[index], g, origin);
-}
-
-// ------------------------------------------------- f32 radiometry (fast) --
-// In fast mode positions, ray directions and hit distances stay f64, but the quantities that only weight a
-// path -- sampled local directions, cosines, pdf values, albedo * scattering_pdf / pdf -- are evaluated in f32
-// on the single-instruction rcp / rsq / sqrt / sin / cos units. Differences that are cancellation-prone
-// (point - centre, |oc|^2 - r^2) are formed in f64 first and only then narrowed.
-struct F3 {
-    float x, y, z;
-};
-PT_DEV F3 f3(float x, float y, float z) { return F3{x, y, z}; }
-PT_DEV F3 to_f3(D3 a) { return F3{(float)a.x, (float)a.y, (float)a.z}; }
-PT_DEV D3 to_d3(F3 a) { return D3{(double)a.x, (double)a.y, (double)a.z}; }
-PT_DEV F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
-PT_DEV float dotf(F3 a, F3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-PT_DEV F3 crossf(F3 a, F3 b) { // src/math/vec3.rs:137-143
-    return F3{a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x};
-}
-PT_DEV F3 unitf(F3 a) { return a * __builtin_amdgcn_rsqf(dotf(a, a)); }
-struct OnbF {
-    F3 u, v, w;
-};
-PT_DEV OnbF onbf_from_w(F3 n) { // src/onb.rs:18-33
-    F3 w = unitf(n);
-    F3 a = __builtin_fabsf(w.x) > 0.9f ? f3(0.f, 1.f, 0.f) : f3(1.f, 0.f, 0.f);
-    F3 v = unitf(crossf(w, a));
-    F3 u = crossf(w, v);
-    return OnbF{u, v, w};
-}
-PT_DEV F3 onbf_local(const OnbF &b, F3 a) {
-    return F3{__builtin_fmaf(b.w.x, a.z, __builtin_fmaf(b.v.x, a.y, b.u.x * a.x)),
-              __builtin_fmaf(b.w.y, a.z, __builtin_fmaf(b.v.y, a.y, b.u.y * a.x)),
-              __builtin_fmaf(b.w.z, a.z, __builtin_fmaf(b.v.z, a.y, b.u.z * a.x))};
-}
-// One light shape: Hitable::random (src/sphere.rs:96-101 with 16-25, src/rect.rs:135-144, default hitable.rs:33-35),
-// and the cosine lobe. Both take the raw bits u1, u2 of the NEXT two draws of `g` (Rng::peek_u32), which the caller has
-// computed once for every lane of the wave, whichever sampler a lane ends up in; a sampler that uses them consumes
-// them (g.n += 2), one that draws nothing (the default Hitable::random) leaves the stream where it is.
-PT_DEV float bits_to_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); } // Rng::nextf
-PT_DEV double bits_to_f64(uint32_t u) { return (double)u * (1.0 / 4294967296.0); }     // Rng::next
-PT_DEV F3 random_cosine_direction_f(uint32_t u1, uint32_t u2, Rng &g) { // src/material.rs:10-19
-    g.n += 2;
-    const float r1 = bits_to_f32(u1);
-    const float r2 = bits_to_f32(u2);
-    const float z = __builtin_amdgcn_sqrtf(1.0f - r2);
-    const float r2_sqrt = __builtin_amdgcn_sqrtf(r2);
-    return f3(__builtin_amdgcn_cosf(r1) * r2_sqrt, __builtin_amdgcn_sinf(r1) * r2_sqrt, z);
-}
-PT_DEV D3 light_random_fast(const DevLight &l, uint32_t u1, uint32_t u2, Rng &g, D3 origin) {
-    if (l.kind == LIGHT_SPHERE) {
-        g.n += 2;
-        const D3 direction = d3(l.d[0], l.d[1], l.d[2]) - origin;
-        const float distance_sq = (float)squared_length(direction);
-        const OnbF uvw = onbf_from_w(to_f3(direction));
-        const float r1 = bits_to_f32(u1);
-        const float r2 = bits_to_f32(u2);
-        const float radius = (float)l.d[3];
-        const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(1.0f - radius * radius * __builtin_amdgcn_rcpf(distance_sq)) - 1.0f);
-        const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
-        return to_d3(onbf_local(uvw, f3(__builtin_amdgcn_cosf(r1) * c, __builtin_amdgcn_sinf(r1) * c, z)));
-    }
-    if (l.kind == LIGHT_RECT) {
-        g.n += 2;
-        const double random_a = __builtin_fma(bits_to_f64(u1), l.d[1] - l.d[0], l.d[0]);
-        const double random_b = __builtin_fma(bits_to_f64(u2), l.d[3] - l.d[2], l.d[2]);
-        const D3 p = l.axis == 0 ? d3(l.d[4], random_a, random_b)
-                                 : (l.axis == 1 ? d3(random_a, l.d[4], random_b) : d3(random_a, random_b, l.d[4]));
-        return p - origin;
-    }
-    return d3(1.0, 0.0, 0.0);
-}
-// One light shape: Hitable::pdf_value (src/sphere.rs:87-95, src/rect.rs:124-133, default hitable.rs:30-32).
-// `dir` is the f32 copy of the direction, `len2` its squared length.
-PT_DEV float light_pdf_value_fast(const DevLight &l, D3 origin, F3 dir, float len2) {
-    if (l.kind == LIGHT_SPHERE) {
-        const D3 ocd = origin - d3(l.d[0], l.d[1], l.d[2]);
-        const double dsq_d = M<false>::squared_length(ocd);
-        const float cc = (float)__builtin_fma(-l.d[3], l.d[3], dsq_d); // |oc|^2 - r^2 without f32 cancellation
-        const F3 oc = to_f3(ocd);
-        const float b = dotf(oc, dir);
-        const float disc = __builtin_fmaf(-len2, cc, b * b);
-        bool hit = false;
-        if (disc > 0.0f) {
-            const float root = __builtin_amdgcn_sqrtf(disc);
-            const float inv_a = __builtin_amdgcn_rcpf(len2);
-            const float t0 = (-b - root) * inv_a, t1 = (-b + root) * inv_a;
-            hit = (t0 > 0.001f) || (t1 > 0.001f); // t < f64::MAX always holds for finite t
-        }
-        if (!hit) return 0.0f;
-        const float dsq = (float)dsq_d;
-        // 1 - cos_theta_max with cos_theta_max = sqrt(1 - r^2/d^2) = sqrt(cc/d^2), written without cancellation
-        const float inv_dsq = __builtin_amdgcn_rcpf(dsq);
-        const float cos_theta_max = __builtin_amdgcn_sqrtf(cc * inv_dsq);
-        const float one_minus = ((float)(l.d[3] * l.d[3]) * inv_dsq) * __builtin_amdgcn_rcpf(1.0f + cos_theta_max);
-        return __builtin_amdgcn_rcpf(6.2831853071795864769f * one_minus);
-    }
-    if (l.kind == LIGHT_RECT) {
-        const double ok = l.axis == 0 ? origin.x : (l.axis == 1 ? origin.y : origin.z);
-        const float dk = l.axis == 0 ? dir.x : (l.axis == 1 ? dir.y : dir.z);
-        const float t = (float)(l.d[4] - ok) * __builtin_amdgcn_rcpf(dk);
-        if (t < 0.001f || t > 3.0e38f) return 0.0f; // a NaN t passes, as in the reference (src/rect.rs:99)
-        F3 rel; // in-plane coordinates of the hit relative to the rectangle's low corner, formed in f64
-        if (l.axis == 0) rel = f3((float)(origin.y - l.d[0]), (float)(origin.z - l.d[2]), 0.f);
-        else if (l.axis == 1) rel = f3((float)(origin.x - l.d[0]), (float)(origin.z - l.d[2]), 0.f);
-        else rel = f3((float)(origin.x - l.d[0]), (float)(origin.y - l.d[2]), 0.f);
-        const float da = l.axis == 0 ? dir.y : dir.x;
-        const float db = l.axis == 2 ? dir.y : dir.z;
-        const float a = __builtin_fmaf(t, da, rel.x), b = __builtin_fmaf(t, db, rel.y);
-        const float wa = (float)(l.d[1] - l.d[0]), wb = (float)(l.d[3] - l.d[2]);
-        if (a < 0.0f || a > wa || b < 0.0f || b > wb) return 0.0f;
-        const float distance_sq = t * t * len2;
-        const float cosine = __builtin_fabsf(dk * __builtin_amdgcn_rsqf(len2));
-        return distance_sq * __builtin_amdgcn_rcpf(cosine * (wa * wb));
-    }
-    return 0.0f;
 }
 
 // ------------------------------------------------------------- materials --
@@ -840,18 +840,18 @@ template <bool X> PT_DEV double schlick(double cosine, double ref_idx) { // src/
 }
 
 // The material's texture at a hit: the colour inlined in the leaf record, or the general evaluator.
-PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec) {
-    if (lf.texture < 0) return d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
-    return texture_value(sv, lf.texture, rec.u, rec.v, rec.p);
+template <int TEX> PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec) {
+    if (TEX == 0 || lf.texture < 0) return d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
+    return texture_value<TEX>(sv, lf.texture, rec.u, rec.v, rec.p);
 }
 // Material::emitted (src/material.rs:145-147 default, 303-305 Lambertian, 325-331 DiffuseLight).
-PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec) {
+template <int TEX> PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec) {
     if (lf.mat_kind == PT_M_LAMBERTIAN) {
-        if (lf.emissive > 0.0) return leaf_texture(sv, lf, rec) * lf.emissive;
+        if (lf.emissive > 0.0) return leaf_texture<TEX>(sv, lf, rec) * lf.emissive;
         return d3(0.0, 0.0, 0.0);
     }
     if (lf.mat_kind == PT_M_DIFFUSE_LIGHT) {
-        if (dot(rec.n, ray_d) < 0.0) return leaf_texture(sv, lf, rec);
+        if (dot(rec.n, ray_d) < 0.0) return leaf_texture<TEX>(sv, lf, rec);
         return d3(0.0, 0.0, 0.0);
     }
     return d3(0.0, 0.0, 0.0);

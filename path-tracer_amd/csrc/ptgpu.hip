@@ -21,7 +21,9 @@
 #include <deque>
 #include <mutex>
 #include <new>
+#include <cstddef>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "accel.h"
@@ -97,7 +99,7 @@ struct pt_ctx {
     bool have_scene = false, have_camera = false;
     FlatScene flat;
     SceneView view{};
-    bool need_uv = false;
+    int tex = 0; // texture level of the uploaded scene: 0 constant colours only, 1 checker / noise, 2 image textures too
     void *d_ops = nullptr, *d_xforms = nullptr, *d_leaves = nullptr, *d_lights = nullptr, *d_materials = nullptr,
          *d_textures = nullptr, *d_texels = nullptr, *d_perlin = nullptr;
     CameraDev cam{};
@@ -133,7 +135,7 @@ struct pt_ctx {
     bool use_scan = false;         // wave-uniform extend for short op streams
     int scan_max_ops = 96;
     bool scan_list = false;        // ... over the stream with its BOX ops removed
-    bool fuse = true;              // trace inside the shade kernel when scan_list applies (PTGPU_FUSE=0 disables)
+    bool fuse = true;              // short box-free lists are traced and shaded in one kernel (off: PT_PASS_PER_BOUNCE)
     int list_max_leaves = 24;
     void *d_ops_list = nullptr;
     int32_t n_list_ops = 0;
@@ -155,9 +157,7 @@ struct pt_ctx {
     bool accel_pool_from_set = false;
     uint32_t accel_grid = 2;     // workgroups per resident slot
     uint32_t accel_inner = 24;   // lanes on inner nodes below which a wave turns to its leaves
-    bool fuse_first = true;        // bounce 0 of an offline fused pass generates its own rays (PTGPU_FUSE_FIRST=0 disables)
-    uint32_t persistent_max_paths = 1u << 23;
-    bool persistent = true;        // fused scenes: one launch per pass (PTGPU_PERSISTENT=0: one launch per bounce)
+    uint32_t shards = 8;           // shards of the render queues
     bool use_accel = true;         // fast mode: SAH tree for scenes that are not a short list (PTGPU_ACCEL=0 disables)
     bool accel_ok = false;
     void *d_accel_nodes = nullptr, *d_accel_prims = nullptr, *d_accel_parent = nullptr, *d_accel_levels = nullptr;
@@ -214,15 +214,10 @@ int grid_for(const pt_ctx *ctx, uint64_t n) {
 
 int alloc_path_state(pt_ctx *ctx) {
     // whole shards of whole workgroup chunks
-    uint32_t shards = 8, shift = 3; // measured: 64 shards cost 18 % (scattered streams), 8 cost 2 % and leave 8x atomic headroom
-    if (const char *e = std::getenv("PTGPU_SHARDS")) { // 1, 2, 4, ... 64
-        const long v = std::strtol(e, nullptr, 10);
-        if (v >= 1 && v <= (long)kShards && (v & (v - 1)) == 0) {
-            shards = (uint32_t)v;
-            shift = 0;
-            while ((1u << shift) < shards) ++shift;
-        }
-    }
+    // measured: 64 shards cost 18 % (scattered streams), 8 cost 2 % and leave 8x atomic headroom
+    const uint32_t shards = ctx->shards;
+    uint32_t shift = 0;
+    while ((1u << shift) < shards) ++shift;
     const uint32_t per_shard = ((ctx->capacity + kBlock * shards - 1) / (kBlock * shards)) * kBlock;
     ctx->capacity = per_shard * shards;
     ctx->shape.shards = shards;
@@ -337,7 +332,7 @@ void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &
     } else if (!X && ctx->accel_ok && a.counters == nullptr) {
         hipLaunchKernelGGL((k_extend_accel<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
                            (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a);
-    } else if (!X && !FRAMES && ctx->use_scan && ctx->scan_list && ctx->fuse_ok && ctx->fuse && a.counters == nullptr) {
+    } else if (!X && !FRAMES && ctx->use_scan && ctx->scan_list && ctx->fuse_ok && a.counters == nullptr) {
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_fused;
         v.n_traversal_ops = ctx->n_fused_ops;
@@ -364,32 +359,25 @@ void launch_extend(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
     if (ctx->exact) launch_extend_x<true>(ctx, grid, q, a);
     else launch_extend_x<false>(ctx, grid, q, a);
 }
-template <bool X, bool UV, int FUSE>
-void launch_shade_xuf(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
-    SceneView v = ctx->view;
-    if (FUSE) {
-        v.ops = (const DevOp *)ctx->d_ops_fused;
-        v.n_traversal_ops = ctx->n_fused_ops;
-    }
-    hipLaunchKernelGGL((k_shade<X, UV, FUSE>), dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
-                       ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, v, ctx->d_hit_t,
-                       ctx->d_hit_id, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth, ctx->render_flags);
+// Calls f with the context's texture level as a compile-time constant (std::integral_constant<int, 0 | 1 | 2>).
+template <class F> void with_tex(int tex, F &&f) {
+    if (tex == 0) f(std::integral_constant<int, 0>{});
+    else if (tex == 1) f(std::integral_constant<int, 1>{});
+    else f(std::integral_constant<int, 2>{});
 }
-// fused = trace inside the shade kernel (fast mode, box-free list, no transformed subtrees)
-void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth, bool fused) {
-    if (ctx->exact) {
-        if (ctx->need_uv) launch_shade_xuf<true, true, 0>(ctx, grid, qi, qo, d, max_depth);
-        else launch_shade_xuf<true, false, 0>(ctx, grid, qi, qo, d, max_depth);
-    } else if (!fused) {
-        if (ctx->need_uv) launch_shade_xuf<false, true, 0>(ctx, grid, qi, qo, d, max_depth);
-        else launch_shade_xuf<false, false, 0>(ctx, grid, qi, qo, d, max_depth);
-    } else if (ctx->view.has_medium) {
-        if (ctx->need_uv) launch_shade_xuf<false, true, 2>(ctx, grid, qi, qo, d, max_depth);
-        else launch_shade_xuf<false, false, 2>(ctx, grid, qi, qo, d, max_depth);
-    } else {
-        if (ctx->need_uv) launch_shade_xuf<false, true, 1>(ctx, grid, qi, qo, d, max_depth);
-        else launch_shade_xuf<false, false, 1>(ctx, grid, qi, qo, d, max_depth);
-    }
+
+void launch_shade(pt_ctx *ctx, int grid, const Queue &qi, const Queue &qo, uint32_t d, uint32_t max_depth) {
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, qi, qo, ctx->shape,
+                           ctx->d_counts + (size_t)d * kShards, ctx->d_counts + (size_t)(d + 1) * kShards, ctx->view,
+                           ctx->d_hit_t, ctx->d_hit_id, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], d, max_depth,
+                           ctx->render_flags);
+    };
+    with_tex(ctx->tex, [&](auto T) {
+        constexpr int kTex = decltype(T)::value;
+        if (ctx->exact) launch(k_shade<true, kTex>);
+        else launch(k_shade<false, kTex>);
+    });
 }
 
 // Workgroups for bounce d of a pass over n paths. Kernels grid-stride over the device-side queue size, so any
@@ -426,21 +414,18 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(iters + 1) * kShards * sizeof(uint32_t), st));
     const int g_all = grid_for(ctx, n);
-    // Measured on the Cornell box, one launch per pass against one per bounce: 2^20 paths +53 %, 2^22 +13 %,
-    // 2^24 -3 %, 2^26 -7 % (the global compaction keeps every wave's tiles full and spreads the tail of long
-    // paths over the whole chip); a 1080p realtime frame (0.4 M paths) +11 %.
-    // (realtime frames, 0.4 M paths after the pixel skip, measured 16 % slower through the pool than through the
-    // persistent form below: four of five generated samples are skipped)
+    // One launch per pass wherever a form for it exists. Offline passes keep their paths in registers (the pool
+    // kernels). Realtime frames hold 0.4 M paths after the 80 % pixel skip; through the pool they measured 16 %
+    // slower than through the persistent queue form below (four of five generated samples are skipped), which in
+    // turn measured +53 % at 2^20 paths, +13 % at 2^22, -3 % at 2^24 against a launch per bounce.
     const bool pool = fused && ctx->path_pool && !realtime;
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
                        ctx->view.n_leaves <= kLdsLeaves;
     const bool tree = !fused && !realtime && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count;
-    const bool persistent = fused && !pool && ctx->persistent && n <= ctx->persistent_max_paths;
+    const bool persistent = fused && !pool;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
-    // offline passes of fused scenes with a launch per bounce: bounce 0 generates its own rays
-    const bool gen0 = fused && !pool && !persistent && !realtime && ctx->fuse_first;
     HIP_TRY(ctx, mark());
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
@@ -450,19 +435,6 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     };
     if (pool || tree || xpool) {
         // no ray generation launch: the pool kernels make their own camera samples
-    } else if (gen0) {
-        SceneView v = ctx->view;
-        v.ops = (const DevOp *)ctx->d_ops_fused;
-        v.n_traversal_ops = ctx->n_fused_ops;
-        const bool media = ctx->view.has_medium != 0;
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(g_all), dim3(kBlock), 0, st, ctx->q[1], ctx->shape, ctx->d_counts, v, ctx->cam,
-                               pp, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->render_flags);
-        };
-        if (media && ctx->need_uv) launch(k_first_bounce<true, 2>);
-        else if (media) launch(k_first_bounce<false, 2>);
-        else if (ctx->need_uv) launch(k_first_bounce<true, 1>);
-        else launch(k_first_bounce<false, 1>);
     } else if (realtime)
         hipLaunchKernelGGL(k_raygen<true>, dim3(g_all), dim3(kBlock), 0, st, ctx->q[0], gen_shape,
                            ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->cam, pp, ctx->d_counts);
@@ -487,10 +459,11 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->q[0], ctx->q[1], ctx->d_counts, v,
                                ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], pp.max_depth, ctx->render_flags);
         };
-        if (media && ctx->need_uv) launch(k_trace_persistent<true, 2>);
-        else if (media) launch(k_trace_persistent<false, 2>);
-        else if (ctx->need_uv) launch(k_trace_persistent<true, 1>);
-        else launch(k_trace_persistent<false, 1>);
+        with_tex(ctx->tex, [&](auto T) {
+            constexpr int kTex = decltype(T)::value;
+            if (media) launch(k_trace_persistent<kTex, 2>);
+            else launch(k_trace_persistent<kTex, 1>);
+        });
         HIP_TRY(ctx, mark());
     }
     if (pool || xpool) {
@@ -513,21 +486,20 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
                                ctx->pool_refill, chunk);
         };
-        if (xpool) {
-            v = ctx->view; // the reference's own tree
-            if (media && ctx->need_uv) launch(k_path_pool<true, 2, true>);
-            else if (media) launch(k_path_pool<false, 2, true>);
-            else if (ctx->need_uv) launch(k_path_pool<true, 1, true>);
-            else launch(k_path_pool<false, 1, true>);
-        } else if (media && ctx->need_uv) launch(k_path_pool<true, 2>);
-        else if (media) launch(k_path_pool<false, 2>);
-        else if (ctx->need_uv) launch(k_path_pool<true, 1>);
-        else launch(k_path_pool<false, 1>);
+        if (xpool) v = ctx->view; // the reference's own tree
+        with_tex(ctx->tex, [&](auto T) {
+            constexpr int kTex = decltype(T)::value;
+            if (xpool) {
+                if (media) launch(k_path_pool<kTex, 2, true>);
+                else launch(k_path_pool<kTex, 1, true>);
+            } else if (media) launch(k_path_pool<kTex, 2>);
+            else launch(k_path_pool<kTex, 1>);
+        });
         HIP_TRY(ctx, mark());
     }
     if (tree) {
         const uint32_t tiles = (n + 63u) / 64u;
-        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->need_uv ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
+        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
         const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
@@ -542,10 +514,11 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                (const DevOp *)ctx->d_accel_prims, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
                                ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
         };
-        if (media && ctx->need_uv) launch(k_tree_pool<true, true>);
-        else if (media) launch(k_tree_pool<false, true>);
-        else if (ctx->need_uv) launch(k_tree_pool<true, false>);
-        else launch(k_tree_pool<false, false>);
+        with_tex(ctx->tex, [&](auto T) {
+            constexpr int kTex = decltype(T)::value;
+            if (media) launch(k_tree_pool<kTex, true>);
+            else launch(k_tree_pool<kTex, false>);
+        });
         HIP_TRY(ctx, mark());
     }
     const bool one_launch = persistent || pool || tree || xpool;
@@ -565,10 +538,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         ea.hit_id = ctx->d_hit_id;
         ea.counters = count ? ctx->d_trav : nullptr;
         HIP_TRY(ctx, mark());
-        if (!fused) launch_extend(ctx, g_d, qi, ea);
+        launch_extend(ctx, g_d, qi, ea);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
-        if (!(gen0 && d == 0)) launch_shade(ctx, g_d, qi, qo, d, pp.max_depth, fused);
+        launch_shade(ctx, g_d, qi, qo, d, pp.max_depth);
         HIP_TRY(ctx, mark());
     }
     HIP_TRY(ctx, mark());
@@ -578,12 +551,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
     ctx->stats.paths += n;
-    ctx->stats.launches_raygen += (gen0 || pool || tree || xpool) ? 0 : 1;
+    ctx->stats.launches_raygen += (pool || tree || xpool) ? 0 : 1;
     ctx->stats.launches_extend += (fused || tree || xpool) ? 0 : iters;
-    ctx->stats.launches_shade += one_launch ? 1 : (gen0 ? iters - 1 : iters);
+    ctx->stats.launches_shade += one_launch ? 1 : iters;
     ctx->stats.launches_resolve += 1;
     ctx->stats.last_pass_form = tree ? PT_PASS_TREE_POOL : (pool || xpool) ? PT_PASS_PATH_POOL : persistent ? PT_PASS_PERSISTENT
-                                : fused ? PT_PASS_PER_BOUNCE_FUSED : PT_PASS_PER_BOUNCE;
+                                : PT_PASS_PER_BOUNCE;
     if (profile || (read_counts && !one_launch)) { // the one-launch forms size no grids from the counts
         ctx->h_shard_counts.resize((size_t)(iters + 1) * kShards);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_shard_counts.data(), ctx->d_counts,
@@ -602,7 +575,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             return (double)ms;
         };
         size_t k = 0;
-        ctx->stats.ms_raygen += elapsed(k); // with gen0 this launch is k_first_bounce: ray generation AND bounce 0
+        ctx->stats.ms_raygen += elapsed(k);
         k += 2;
         for (uint32_t d = 0; d < (one_launch ? 1u : iters); ++d) {
             ctx->stats.ms_extend += elapsed(k);
@@ -610,14 +583,84 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             ctx->stats.ms_shade += elapsed(k);
             k += 2;
         }
-        // segments of the launches timed as extend / shade (bounce 0 belongs to k_first_bounce when it ran)
-        for (uint32_t d = gen0 ? 1u : 0u; d < iters; ++d) ctx->stats.profiled_segments += ctx->h_counts[d];
+        // segments of the launches timed as extend / shade
+        for (uint32_t d = 0; d < iters; ++d) ctx->stats.profiled_segments += ctx->h_counts[d];
         ctx->stats.ms_resolve += elapsed(k);
         ctx->stats.profiled_paths += n;
         ctx->stats.profiled_passes += 1;
-        ctx->stats.profiled_bounce_launches += one_launch ? 1 : (gen0 ? iters - 1 : iters);
+        ctx->stats.profiled_bounce_launches += one_launch ? 1 : iters;
     }
     return PT_OK;
+}
+
+// pt_tuning -> context. A zero field keeps the library default. Returns false on a value outside its range.
+bool apply_tuning(pt_ctx *ctx, const pt_tuning &t) {
+    auto in = [](uint32_t v, uint32_t lo, uint32_t hi) { return v >= lo && v <= hi; };
+    switch (t.pass_form) {
+    case PT_PASS_NONE: break;
+    case PT_PASS_PER_BOUNCE: // every stage its own launch: no pools, no fused trace + shade
+        ctx->fuse = ctx->path_pool = ctx->tree_pool = ctx->exact_pool = false;
+        break;
+    case PT_PASS_PERSISTENT: // list scenes through the persistent queue form, offline passes included
+        ctx->path_pool = false;
+        break;
+    case PT_PASS_PATH_POOL:
+    case PT_PASS_TREE_POOL: break; // what offline passes use anyway
+    default: return false;
+    }
+    if (t.pool_refill) { if (!in(t.pool_refill, 1, 64)) return false; ctx->pool_refill = t.pool_refill; }
+    if (t.pool_chunk) { if (!in(t.pool_chunk, 64, 1u << 20)) return false; ctx->pool_chunk = t.pool_chunk; }
+    if (t.pool_grid) { if (!in(t.pool_grid, 1, 256)) return false; ctx->pool_grid = t.pool_grid; }
+    // a refill threshold above 64 would never be met: the kernel could not end
+    if (t.tree_refill) { if (!in(t.tree_refill, 1, 64)) return false; ctx->tree_tuning[0] = t.tree_refill; }
+    if (t.tree_inner) { if (!in(t.tree_inner, 1, 64)) return false; ctx->tree_tuning[1] = t.tree_inner; }
+    if (t.tree_shade) { if (!in(t.tree_shade, 1, 64)) return false; ctx->tree_tuning[2] = t.tree_shade; }
+    if (t.tree_trav_plus1) { if (!in(t.tree_trav_plus1, 1, 65)) return false; ctx->tree_tuning[3] = t.tree_trav_plus1 - 1; }
+    if (t.accel_form) {
+        if (!in(t.accel_form, 1, 2)) return false;
+        ctx->accel_pool = t.accel_form == 2;
+        ctx->accel_pool_from = 0;
+        ctx->accel_pool_from_set = true;
+    }
+    if (t.accel_refill) { if (!in(t.accel_refill, 1, 64)) return false; ctx->accel_refill = t.accel_refill; }
+    if (t.accel_inner) { if (!in(t.accel_inner, 1, 65)) return false; ctx->accel_inner = t.accel_inner; }
+    if (t.accel_grid) { if (!in(t.accel_grid, 1, 8)) return false; ctx->accel_grid = t.accel_grid; }
+    if (t.shards) { if (!in(t.shards, 1, kShards) || (t.shards & (t.shards - 1))) return false; ctx->shards = t.shards; }
+    if (t.scan_max_ops_plus1) ctx->scan_max_ops = (int)std::min<uint32_t>(t.scan_max_ops_plus1 - 1, 1u << 30);
+    if (t.list_max_leaves_plus1) ctx->list_max_leaves = (int)std::min<uint32_t>(t.list_max_leaves_plus1 - 1, 1u << 30);
+    if (t.profile_period) ctx->profile_period = t.profile_period;
+    return true;
+}
+
+// PTGPU_TUNING="field=value,field=value": overrides fields of pt_tuning by name, for A/B runs of a host that is not
+// rebuilt. Unknown names and unparsable values are ignored.
+void apply_tuning_overrides(pt_tuning &t) {
+    const char *env = std::getenv("PTGPU_TUNING");
+    if (!env) return;
+    static const struct { const char *name; uint32_t pt_tuning::*field; } kFields[] = {
+        {"pass_form", &pt_tuning::pass_form}, {"pool_refill", &pt_tuning::pool_refill}, {"pool_chunk", &pt_tuning::pool_chunk},
+        {"pool_grid", &pt_tuning::pool_grid}, {"tree_refill", &pt_tuning::tree_refill}, {"tree_inner", &pt_tuning::tree_inner},
+        {"tree_shade", &pt_tuning::tree_shade}, {"tree_trav_plus1", &pt_tuning::tree_trav_plus1},
+        {"accel_form", &pt_tuning::accel_form}, {"accel_refill", &pt_tuning::accel_refill},
+        {"accel_inner", &pt_tuning::accel_inner}, {"accel_grid", &pt_tuning::accel_grid}, {"shards", &pt_tuning::shards},
+        {"scan_max_ops_plus1", &pt_tuning::scan_max_ops_plus1}, {"list_max_leaves_plus1", &pt_tuning::list_max_leaves_plus1},
+        {"profile_period", &pt_tuning::profile_period}};
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+        size_t end = all.find(',', pos);
+        if (end == std::string::npos) end = all.size();
+        const std::string kv = all.substr(pos, end - pos);
+        const size_t eq = kv.find('=');
+        if (eq != std::string::npos)
+            for (const auto &f : kFields)
+                if (kv.compare(0, eq, f.name) == 0 && std::strlen(f.name) == eq) {
+                    char *stop = nullptr;
+                    const unsigned long v = std::strtoul(kv.c_str() + eq + 1, &stop, 10);
+                    if (stop && *stop == '\0') t.*(f.field) = (uint32_t)v;
+                }
+        pos = end + 1;
+    }
 }
 
 } // namespace
@@ -628,7 +671,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
 extern "C" {
 
 int pt_create(const pt_config *cfg, pt_ctx **out) {
-    if (!cfg || !out || cfg->struct_size != sizeof(pt_config)) return PT_ERR_INVALID_ARG;
+    // the structure of ABI version 1 ended before `tuning`: still accepted, with the defaults
+    if (!cfg || !out || (cfg->struct_size != sizeof(pt_config) && cfg->struct_size != offsetof(pt_config, tuning)))
+        return PT_ERR_INVALID_ARG;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return PT_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= n_dev) return PT_ERR_INVALID_ARG;
@@ -638,40 +683,16 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     ctx->seed = cfg->seed;
     ctx->flags = cfg->flags;
     ctx->exact = (cfg->flags & PT_CFG_EXACT) != 0;
-    if (const char *e = std::getenv("PTGPU_SCAN_MAX_OPS")) ctx->scan_max_ops = (int)std::strtol(e, nullptr, 10);
-    if (const char *e = std::getenv("PTGPU_LIST_MAX_LEAVES")) ctx->list_max_leaves = (int)std::strtol(e, nullptr, 10);
-    if (const char *e = std::getenv("PTGPU_FUSE")) ctx->fuse = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_ACCEL")) ctx->use_accel = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_FUSE_FIRST")) ctx->fuse_first = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_PERSISTENT")) ctx->persistent = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_PERSISTENT_MAX_PATHS")) ctx->persistent_max_paths = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char *e = std::getenv("PTGPU_ACCEL_POOL")) ctx->accel_pool = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_ACCEL_POOL_FROM")) {
-        ctx->accel_pool_from = (uint32_t)std::max(0l, std::strtol(e, nullptr, 10));
-        ctx->accel_pool_from_set = true;
+    pt_tuning tune;
+    std::memset(&tune, 0, sizeof(tune));
+    if (cfg->struct_size == sizeof(pt_config)) tune = cfg->tuning;
+    apply_tuning_overrides(tune); // PTGPU_TUNING, for A/B runs of an unmodified host
+    if (!apply_tuning(ctx, tune)) {
+        delete ctx;
+        return PT_ERR_INVALID_ARG;
     }
-    if (const char *e = std::getenv("PTGPU_ACCEL_GRID")) ctx->accel_grid = (uint32_t)std::min(8l, std::max(1l, std::strtol(e, nullptr, 10)));
-    if (const char *e = std::getenv("PTGPU_ACCEL_INNER")) ctx->accel_inner = (uint32_t)std::min(65l, std::max(1l, std::strtol(e, nullptr, 10)));
-    if (const char *e = std::getenv("PTGPU_ACCEL_REFILL")) ctx->accel_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
-    if (const char *e = std::getenv("PTGPU_TREE_POOL")) ctx->tree_pool = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_TREE_TUNING")) { // "refill,inner,shade,trav"
-        unsigned v[4];
-        if (std::sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
-            for (int k = 0; k < 4; ++k) // a refill threshold above 64 would never be met: the kernel could not end
-                ctx->tree_tuning[k] = std::min(64u, std::max(k == 3 ? 0u : 1u, v[k]));
-    }
-    if (const char *e = std::getenv("PTGPU_EXACT_POOL")) ctx->exact_pool = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_PATH_POOL")) ctx->path_pool = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("PTGPU_POOL_REFILL")) ctx->pool_refill = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
-    if (const char *e = std::getenv("PTGPU_POOL_CHUNK")) ctx->pool_chunk = (uint32_t)std::min(1l << 20, std::max(64l, std::strtol(e, nullptr, 10)));
-    if (const char *e = std::getenv("PTGPU_POOL_GRID")) ctx->pool_grid = (uint32_t)std::min(256l, std::max(1l, std::strtol(e, nullptr, 10)));
-    if (const char *e = std::getenv("PTGPU_PERSIST_FACTOR")) ctx->persist_factor = (uint32_t)std::max(1l, std::strtol(e, nullptr, 10));
     ctx->capacity = cfg->max_paths_in_flight ? cfg->max_paths_in_flight : kDefaultPathsInFlight;
     if (ctx->capacity < 1024) ctx->capacity = 1024;
-    if (const char *e = std::getenv("PTGPU_PROFILE_PERIOD")) {
-        long v = std::strtol(e, nullptr, 10);
-        if (v >= 1) ctx->profile_period = (uint32_t)v;
-    }
     auto bail = [&](int code) {
         pt_destroy(ctx);
         return code;
@@ -759,9 +780,21 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     v.has_isotropic = 0;
     for (int i = 0; i < scene->n_materials; ++i)
         if (scene->materials[i].kind == PT_M_ISOTROPIC) v.has_isotropic = 1;
-    ctx->need_uv = false;
-    for (int i = 0; i < scene->n_textures; ++i)
-        if (scene->textures[i].kind == PT_T_IMAGE) ctx->need_uv = true;
+    // texture level: what the leaves' materials still have to evaluate at a hit (constant colours are in the leaves)
+    ctx->tex = 0;
+    for (const DevLeaf &lf : f.leaves) {
+        if (lf.texture < 0) continue;
+        std::vector<int> todo{lf.texture}; // a checker's children count too
+        for (size_t k = 0; k < todo.size() && k < 64; ++k) {
+            const pt_texture &t = scene->textures[todo[k]];
+            if (t.kind == PT_T_IMAGE) ctx->tex = 2;
+            else if (t.kind != PT_T_CONSTANT) ctx->tex = std::max(ctx->tex, 1);
+            if (t.kind == PT_T_CHECKER) {
+                todo.push_back(t.even);
+                todo.push_back(t.odd);
+            }
+        }
+    }
     ctx->use_scan = f.n_traversal_ops <= ctx->scan_max_ops;
     // In the wave-uniform traversal a primitive is tested as soon as ONE lane of the wave wants it, so a box test
     // only pays when all 64 rays miss the box. For a handful of primitives that almost never happens, and the box

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(ptgpu.EXPORTS), declared ^ set(ptgpu.EXPORTS)
     for name in declared:
         assert hasattr(ptgpu.lib, name), name
-    assert ptgpu.lib.pt_abi_version() == 1
+    assert ptgpu.lib.pt_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
@@ -54,6 +54,21 @@ def test_create_without_gpu_reports_no_device():
     with pytest.raises(ptgpu.PtError) as e:
         ptgpu.Context()
     assert e.value.code == ptgpu.PT_ERR_NO_DEVICE
+
+
+def test_config_sizes_accepted_by_pt_create():
+    """pt_create checks pt_config.struct_size before anything else: the current size and the ABI-1 size (which ended
+    before `tuning`) get as far as the device probe, anything else is an invalid argument."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    for size, want in ((C.sizeof(ptgpu.Config), ptgpu.PT_ERR_NO_DEVICE), (ptgpu.Config.tuning.offset, ptgpu.PT_ERR_NO_DEVICE),
+                       (8, ptgpu.PT_ERR_INVALID_ARG), (C.sizeof(ptgpu.Config) + 4, ptgpu.PT_ERR_INVALID_ARG)):
+        cfg = ptgpu.Config(size, 0, 1, 0, 0)
+        assert ptgpu.lib.pt_create(C.byref(cfg), C.byref(h)) == want, size
+    assert ptgpu.Config.tuning.offset == 24 and C.sizeof(ptgpu.Tuning) == 4 * len(ptgpu.TUNING_FIELDS)
 
 
 def test_builder_rejects_what_the_reference_panics_on():
