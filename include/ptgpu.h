@@ -42,7 +42,8 @@ typedef enum pt_status {
     PT_ERR_NO_CAMERA = -6,
     PT_ERR_OUT_OF_MEMORY = -7,
     PT_ERR_TOO_LARGE = -8,
-    PT_ERR_MISSING_ASSET = -9 /* a named recipe needs an image that was not registered */
+    PT_ERR_MISSING_ASSET = -9, /* a named recipe needs an image that was not registered */
+    PT_ERR_COMM = -10          /* an RCCL call failed; see pt_last_error */
 } pt_status;
 
 /* ------------------------------------------------------------------------ */
@@ -313,6 +314,37 @@ int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double 
 #define PT_INTERSECT_STATIC_MAX_RAYS 65536
 int pt_intersect_static(pt_ctx *ctx, const pt_ray *d_rays, size_t n, double t_min, double t_max,
                         uint64_t medium_seed, pt_hit *d_hits);
+
+/* ------------------------------------------------------------------------ */
+/* Several GPUs: one context per GPU, one image                              */
+/* ------------------------------------------------------------------------ */
+/* Replaces dealing TraceSceneBatchJobs over the image to the worker threads (src/lib.rs:380-399) and the main thread
+ * reading the shared buffer (src/lib.rs:496-509) when the workers are GPUs: a GROUP is one context per GPU, each
+ * with the same scene and camera. Member r of N traces rows r, r + N, r + 2N, ... of the image into its own copy
+ * (pt_render with the row_step / row_phase that pt_group_rows returns; the RNG is keyed by global pixel and sample, so
+ * the assembled image does not depend on N), and pt_group_gather moves every member's rows into the root's image with
+ * one group of RCCL point-to-point transfers over xGMI (the rows are disjoint: a gather, not a reduction). The root
+ * then presents (pt_readback, pt_tonemap_device, ...).
+ *
+ * Two ways to form a group:
+ *   one process per GPU   rank 0 calls pt_group_unique_id and hands the bytes to the other processes by its own
+ *                         means (torch.distributed, MPI, a file); every process calls pt_group_join (collective);
+ *   one process, N GPUs   pt_group_join_local with the N contexts (distinct devices); gathers with
+ *                         pt_group_gather_local, which issues every member's transfer from the calling thread.
+ * A context alone is a group of one (row_step 1; gathering is a no-op). */
+#define PT_GROUP_ID_BYTES 128
+int pt_group_unique_id(uint8_t *id_out, size_t n_bytes);                   /* n_bytes >= PT_GROUP_ID_BYTES */
+int pt_group_join(pt_ctx *ctx, const uint8_t *id, size_t n_bytes, int rank, int world);
+int pt_group_join_local(pt_ctx *const *ctxs, int n);                       /* ctxs[k] becomes member k of n */
+int pt_group_rows(pt_ctx *ctx, uint32_t *row_step, uint32_t *row_phase);   /* this member's share: world, rank */
+/* Collective over the group: every member calls it (or the one process calls pt_group_gather_local) after rendering
+ * its rows of the same width x height image. Synchronous; on return the root's image holds every row. */
+int pt_group_gather(pt_ctx *ctx, int root);
+int pt_group_gather_local(pt_ctx *const *ctxs, int n, int root);
+int pt_group_leave(pt_ctx *ctx);                                           /* also done by pt_destroy */
+/* Checks the gather's data path on ONE GPU (group of one): the image's odd rows are packed, wiped, sent from the
+ * context to itself through RCCL and scattered back; the image must come out unchanged. */
+int pt_group_loopback(pt_ctx *ctx);
 
 /* ------------------------------------------------------------------------ */
 /* Host-side scene construction (mirrors SceneBuilder / MaterialBuilder)     */

@@ -34,6 +34,8 @@ PT_ERR_NO_CAMERA = -6
 PT_ERR_OUT_OF_MEMORY = -7
 PT_ERR_TOO_LARGE = -8
 PT_ERR_MISSING_ASSET = -9
+PT_ERR_COMM = -10
+PT_GROUP_ID_BYTES = 128
 
 PT_MODE_OFFLINE = 0
 PT_MODE_REALTIME = 1
@@ -239,7 +241,9 @@ EXPORTS = [
     "pt_scene_bvh", "pt_scene_set_root", "pt_scene_set_lights", "pt_scene_bounding_box", "pt_scene_flatten_info",
     "pt_tonemap_rgb8", "pt_tonemap_device", "pt_display_transform", "pt_camera_apply_input", "pt_session_new",
     "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_scene_build_device",
-    "pt_abi_version", "pt_intersect_static", "pt_asset_register_image",
+    "pt_abi_version", "pt_intersect_static", "pt_asset_register_image", "pt_group_unique_id", "pt_group_join",
+    "pt_group_join_local", "pt_group_rows", "pt_group_gather", "pt_group_gather_local", "pt_group_leave",
+    "pt_group_loopback",
 ]
 
 _vp = C.c_void_p
@@ -306,6 +310,14 @@ _sig("pt_scene_accel_info", C.c_int, C.POINTER(SceneDesc), _i32p, _i32p, _i32p)
 _sig("pt_scene_refit", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_scene_build_device", C.c_int, _vp, C.c_double, C.c_double)
 _sig("pt_asset_register_image", C.c_int, C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int)
+_sig("pt_group_unique_id", C.c_int, C.POINTER(C.c_uint8), C.c_size_t)
+_sig("pt_group_join", C.c_int, _vp, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int)
+_sig("pt_group_join_local", C.c_int, C.POINTER(_vp), C.c_int)
+_sig("pt_group_rows", C.c_int, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+_sig("pt_group_gather", C.c_int, _vp, C.c_int)
+_sig("pt_group_gather_local", C.c_int, C.POINTER(_vp), C.c_int, C.c_int)
+_sig("pt_group_leave", C.c_int, _vp)
+_sig("pt_group_loopback", C.c_int, _vp)
 _sig("pt_abi_version", C.c_uint32)
 _sig("pt_intersect_static", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
 PT_INTERSECT_STATIC_MAX_RAYS = 65536
@@ -566,6 +578,27 @@ class Context:
             "pt_intersect_static",
         )
 
+    # ---- groups of contexts, one per GPU (pt_group_*) ----
+    def group_join(self, unique_id: bytes, rank: int, world: int):
+        """Collective over `world` processes; `unique_id` comes from group_unique_id() on one of them."""
+        buf = (C.c_uint8 * PT_GROUP_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(lib.pt_group_join(self._h, buf, PT_GROUP_ID_BYTES, rank, world), "pt_group_join")
+
+    def group_rows(self):
+        """(row_step, row_phase) for pt_render: this member's rows of the image."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(lib.pt_group_rows(self._h, C.byref(a), C.byref(b)), "pt_group_rows")
+        return a.value, b.value
+
+    def group_gather(self, root=0):
+        self._check(lib.pt_group_gather(self._h, root), "pt_group_gather")
+
+    def group_leave(self):
+        self._check(lib.pt_group_leave(self._h), "pt_group_leave")
+
+    def group_loopback(self):
+        self._check(lib.pt_group_loopback(self._h), "pt_group_loopback")
+
     def tonemap_rgb8(self):
         """Reinhard + sqrt gamma + u8 of the context's image on the device, top row first (pt_tonemap_device)."""
         out = np.empty((self.height, self.width, 3), dtype=np.uint8)
@@ -586,6 +619,30 @@ class Context:
 
     def stats_reset(self):
         self._check(lib.pt_stats_reset(self._h), "pt_stats_reset")
+
+
+def group_unique_id() -> bytes:
+    """The identifier one member creates and every member passes to Context.group_join (pt_group_unique_id)."""
+    buf = (C.c_uint8 * PT_GROUP_ID_BYTES)()
+    rc = lib.pt_group_unique_id(buf, PT_GROUP_ID_BYTES)
+    if rc != PT_OK:
+        raise PtError(rc, "pt_group_unique_id")
+    return bytes(buf)
+
+
+def group_join_local(contexts):
+    """One process, one context per GPU: contexts[k] becomes member k (pt_group_join_local)."""
+    arr = (_vp * len(contexts))(*[c._h for c in contexts])
+    rc = lib.pt_group_join_local(arr, len(contexts))
+    if rc != PT_OK:
+        raise PtError(rc, "pt_group_join_local: " + lib.pt_last_error(contexts[0]._h).decode(errors="replace"))
+
+
+def group_gather_local(contexts, root=0):
+    arr = (_vp * len(contexts))(*[c._h for c in contexts])
+    rc = lib.pt_group_gather_local(arr, len(contexts), root)
+    if rc != PT_OK:
+        raise PtError(rc, "pt_group_gather_local: " + lib.pt_last_error(contexts[0]._h).decode(errors="replace"))
 
 
 def copy_camera(cam: Camera) -> Camera:

@@ -12,6 +12,9 @@
 // kernels_shade.h). This file holds the context, the choice of form (run_pass) and the C entry points.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h> // types and prototypes only: the library is loaded on first use, see rccl_api()
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -175,6 +178,10 @@ struct pt_ctx {
     size_t stage_bytes[2] = {0, 0};
     hipEvent_t ev_batch[2] = {nullptr, nullptr}; // bracket the extend launches of a ray batch
     unsigned char *d_static = nullptr;           // this GPU's copy of `scratch` (pt_intersect_static)
+
+    // membership in a group of contexts, one per GPU, that render one image together (pt_group_*)
+    ncclComm_t comm = nullptr;
+    int group_rank = 0, group_world = 1;
 };
 
 namespace {
@@ -593,6 +600,42 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     return PT_OK;
 }
 
+// RCCL is loaded when a group is first formed, not when this library is: a host that never forms a group does not
+// pay for mapping it, and a process that already holds a copy (PyTorch ships its own under the same soname) keeps
+// using that one instead of getting a second.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId;
+    decltype(&ncclCommInitRank) CommInitRank;
+    decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclGroupStart) GroupStart;
+    decltype(&ncclGroupEnd) GroupEnd;
+    decltype(&ncclSend) Send;
+    decltype(&ncclRecv) Recv;
+    decltype(&ncclGetErrorString) GetErrorString;
+};
+const RcclApi *rccl_api() {
+    static const RcclApi *api = []() -> const RcclApi * {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return nullptr;
+        static RcclApi a;
+        bool ok = true;
+        auto sym = [&](auto &fn, const char *name) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, name));
+            ok = ok && fn != nullptr;
+        };
+        sym(a.GetUniqueId, "ncclGetUniqueId");
+        sym(a.CommInitRank, "ncclCommInitRank");
+        sym(a.CommDestroy, "ncclCommDestroy");
+        sym(a.GroupStart, "ncclGroupStart");
+        sym(a.GroupEnd, "ncclGroupEnd");
+        sym(a.Send, "ncclSend");
+        sym(a.Recv, "ncclRecv");
+        sym(a.GetErrorString, "ncclGetErrorString");
+        return ok ? &a : nullptr;
+    }();
+    return api;
+}
 // pt_tuning -> context. A zero field keeps the library default. Returns false on a value outside its range.
 bool apply_tuning(pt_ctx *ctx, const pt_tuning &t) {
     auto in = [](uint32_t v, uint32_t lo, uint32_t hi) { return v >= lo && v <= hi; };
@@ -715,6 +758,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && rccl_api()) (void)rccl_api()->CommDestroy(ctx->comm);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
@@ -1302,6 +1346,204 @@ int pt_stats_reset(pt_ctx *ctx) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_trav, 0, sizeof(TraversalCounters), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pass_counter = 0;
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Groups: one context per GPU, each rendering every world-th row of the same image; the rows are gathered to one
+// member over RCCL (point-to-point sends: the rows are disjoint, nothing is reduced).
+// ---------------------------------------------------------------------------------------------------------------
+#define RCCL_OR_FAIL(ctx)                                                                                         \
+    const RcclApi *nccl = rccl_api();                                                                             \
+    if (!nccl) return set_error(ctx, PT_ERR_COMM, "librccl.so.1 could not be loaded")
+
+#define NCCL_TRY(ctx, expr)                                                                                       \
+    do {                                                                                                          \
+        ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != ncclSuccess) return set_error(ctx, PT_ERR_COMM, std::string(#expr) + ": " + nccl->GetErrorString(r_)); \
+    } while (0)
+
+static uint32_t rows_of_member(uint32_t height, uint32_t world, uint32_t rank) {
+    return rank < height ? (height - rank + world - 1) / world : 0u;
+}
+
+// The gather for the members of the group that live in this process (all of them, or one).
+static int group_gather(pt_ctx *const *m, int n_local, int root) {
+    pt_ctx *first = m[0];
+    const int world = first->group_world;
+    if (root < 0 || root >= world) return set_error(first, PT_ERR_INVALID_ARG, "root outside the group");
+    const uint32_t w = first->width, h = first->height;
+    for (int k = 0; k < n_local; ++k) {
+        pt_ctx *c = m[k];
+        if (!c->comm && world > 1) return set_error(c, PT_ERR_INVALID_ARG, "context is not in a group");
+        if (!c->d_image || c->width != w || c->height != h || w == 0)
+            return set_error(c, PT_ERR_INVALID_ARG, "every member must hold an image of the same size: render first");
+        if (c->group_world != world) return set_error(c, PT_ERR_INVALID_ARG, "members of different groups");
+    }
+    if (world == 1) return PT_OK;
+    RCCL_OR_FAIL(first);
+    const size_t row_bytes = (size_t)w * 4 * sizeof(float);
+    // stage and pack
+    for (int k = 0; k < n_local; ++k) {
+        pt_ctx *c = m[k];
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (c->group_rank == root) {
+            size_t rows = 0;
+            for (int r = 0; r < world; ++r)
+                if (r != root) rows += rows_of_member(h, (uint32_t)world, (uint32_t)r);
+            const int rc = ensure_stage(c, 0, std::max<size_t>(rows * row_bytes, 16));
+            if (rc != PT_OK) return rc;
+        } else {
+            const uint32_t rows = rows_of_member(h, (uint32_t)world, (uint32_t)c->group_rank);
+            const int rc = ensure_stage(c, 0, std::max<size_t>(rows * row_bytes, 16));
+            if (rc != PT_OK) return rc;
+            if (rows)
+                hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(c, (uint64_t)rows * w)), dim3(kBlock), 0, c->stream,
+                                   (const float4 *)c->d_image, w, h, (uint32_t)world, (uint32_t)c->group_rank,
+                                   (float4 *)c->d_stage[0]);
+        }
+    }
+    // one group of point-to-point transfers: every peer has its own xGMI link into the root
+    NCCL_TRY(first, nccl->GroupStart());
+    for (int k = 0; k < n_local; ++k) {
+        pt_ctx *c = m[k];
+        if (c->group_rank == root) {
+            size_t offset = 0;
+            for (int r = 0; r < world; ++r) {
+                if (r == root) continue;
+                const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)r) * w * 4;
+                if (count) NCCL_TRY(c, nccl->Recv((float *)c->d_stage[0] + offset, count, ncclFloat, r, c->comm, c->stream));
+                offset += count;
+            }
+        } else {
+            const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)c->group_rank) * w * 4;
+            if (count) NCCL_TRY(c, nccl->Send(c->d_stage[0], count, ncclFloat, root, c->comm, c->stream));
+        }
+    }
+    NCCL_TRY(first, nccl->GroupEnd());
+    for (int k = 0; k < n_local; ++k) {
+        pt_ctx *c = m[k];
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (c->group_rank == root)
+            hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(c, (uint64_t)w * h)), dim3(kBlock), 0, c->stream,
+                               (float4 *)c->d_image, w, h, (uint32_t)world, (uint32_t)root, (const float4 *)c->d_stage[0]);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
+    return PT_OK;
+}
+
+int pt_group_unique_id(uint8_t *id_out, size_t n_bytes) {
+    if (!id_out || n_bytes < sizeof(ncclUniqueId)) return PT_ERR_INVALID_ARG;
+    const RcclApi *nccl = rccl_api();
+    ncclUniqueId id;
+    if (!nccl || nccl->GetUniqueId(&id) != ncclSuccess) return PT_ERR_COMM;
+    std::memset(id_out, 0, n_bytes);
+    std::memcpy(id_out, &id, sizeof(id));
+    return PT_OK;
+}
+
+int pt_group_join(pt_ctx *ctx, const uint8_t *id, size_t n_bytes, int rank, int world) {
+    if (!ctx || !id || n_bytes < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) return PT_ERR_INVALID_ARG;
+    if (ctx->comm) return set_error(ctx, PT_ERR_INVALID_ARG, "context is in a group already: pt_group_leave first");
+    RCCL_OR_FAIL(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCL_TRY(ctx, nccl->CommInitRank(&ctx->comm, world, uid, rank));
+    ctx->group_rank = rank;
+    ctx->group_world = world;
+    return PT_OK;
+}
+
+int pt_group_join_local(pt_ctx *const *ctxs, int n) {
+    if (!ctxs || n < 1) return PT_ERR_INVALID_ARG;
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k]) return PT_ERR_INVALID_ARG;
+        if (ctxs[k]->comm) return set_error(ctxs[k], PT_ERR_INVALID_ARG, "context is in a group already");
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j]->device == ctxs[k]->device)
+                return set_error(ctxs[k], PT_ERR_INVALID_ARG, "two members on one GPU: RCCL takes one rank per device");
+    }
+    RCCL_OR_FAIL(ctxs[0]);
+    ncclUniqueId uid;
+    NCCL_TRY(ctxs[0], nccl->GetUniqueId(&uid));
+    NCCL_TRY(ctxs[0], nccl->GroupStart());
+    for (int k = 0; k < n; ++k) {
+        HIP_TRY(ctxs[k], hipSetDevice(ctxs[k]->device));
+        NCCL_TRY(ctxs[k], nccl->CommInitRank(&ctxs[k]->comm, n, uid, k));
+    }
+    NCCL_TRY(ctxs[0], nccl->GroupEnd());
+    for (int k = 0; k < n; ++k) {
+        ctxs[k]->group_rank = k;
+        ctxs[k]->group_world = n;
+    }
+    return PT_OK;
+}
+
+int pt_group_rows(pt_ctx *ctx, uint32_t *row_step, uint32_t *row_phase) {
+    if (!ctx || !row_step || !row_phase) return PT_ERR_INVALID_ARG;
+    *row_step = (uint32_t)ctx->group_world;
+    *row_phase = (uint32_t)ctx->group_rank;
+    return PT_OK;
+}
+
+int pt_group_gather(pt_ctx *ctx, int root) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    return group_gather(&ctx, 1, root);
+}
+
+int pt_group_gather_local(pt_ctx *const *ctxs, int n, int root) {
+    if (!ctxs || n < 1) return PT_ERR_INVALID_ARG;
+    for (int k = 0; k < n; ++k)
+        if (!ctxs[k]) return PT_ERR_INVALID_ARG;
+    if (n != ctxs[0]->group_world) return set_error(ctxs[0], PT_ERR_INVALID_ARG, "pt_group_gather_local takes every member of the group");
+    return group_gather(ctxs, n, root);
+}
+
+int pt_group_leave(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (ctx->comm) {
+        RCCL_OR_FAIL(ctx);
+        (void)hipSetDevice(ctx->device);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        NCCL_TRY(ctx, nccl->CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+    }
+    ctx->group_rank = 0;
+    ctx->group_world = 1;
+    return PT_OK;
+}
+
+// Loopback check of the gather's data path on ONE GPU: the image's odd rows are packed as member 1 of a group of two
+// would pack them, cleared in the image, sent from this context to itself through RCCL, and scattered back as member
+// 0 would scatter them. The image must come out unchanged (the caller compares). Needs a group of one (pt_group_join
+// with world 1, or pt_group_join_local with one context).
+int pt_group_loopback(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->comm || ctx->group_world != 1) return set_error(ctx, PT_ERR_INVALID_ARG, "needs a group of one");
+    if (!ctx->d_image || ctx->width == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "no image: render first");
+    RCCL_OR_FAIL(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t w = ctx->width, h = ctx->height;
+    const uint32_t rows = rows_of_member(h, 2u, 1u);
+    if (rows == 0) return PT_OK;
+    const size_t count = (size_t)rows * w * 4;
+    int rc = ensure_stage(ctx, 0, count * sizeof(float));
+    if (rc == PT_OK) rc = ensure_stage(ctx, 1, count * sizeof(float));
+    if (rc != PT_OK) return rc;
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(ctx, (uint64_t)rows * w)), dim3(kBlock), 0, ctx->stream,
+                       (const float4 *)ctx->d_image, w, h, 2u, 1u, (float4 *)ctx->d_stage[1]);
+    for (uint32_t y = 1; y < h; y += 2)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_image + (size_t)y * w * 4, 0xff, (size_t)w * 4 * sizeof(float), ctx->stream));
+    NCCL_TRY(ctx, nccl->GroupStart());
+    NCCL_TRY(ctx, nccl->Send(ctx->d_stage[1], count, ncclFloat, 0, ctx->comm, ctx->stream));
+    NCCL_TRY(ctx, nccl->Recv(ctx->d_stage[0], count, ncclFloat, 0, ctx->comm, ctx->stream));
+    NCCL_TRY(ctx, nccl->GroupEnd());
+    hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(ctx, (uint64_t)w * h)), dim3(kBlock), 0, ctx->stream,
+                       (float4 *)ctx->d_image, w, h, 2u, 0u, (const float4 *)ctx->d_stage[0]);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }
 

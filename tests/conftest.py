@@ -4,6 +4,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  before the library: PyTorch ships its own HIP runtime and RCCL under the same sonames, and a
+#                            process must end up with one copy of each
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -100,3 +100,22 @@ def test_interleaved_rows_gather_matches_single_process(tmp_path, world):
     scene = ptgpu.Scene.named("cornell_box", W / H)
     ref, _ = ob.render(scene.desc(), scene.camera, W, H, SPP, DEPTH, threads=1)
     assert np.array_equal(got, ref, equal_nan=True)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`bench.py --gpus 2` run bare (no launcher, WORLD_SIZE unset) starts two ranks itself. Without a GPU each rank
+    stops at the device check, after the world size has been checked against --gpus."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the rehearsal test")
+    assert proc.returncode != 0
+    assert proc.stdout.count("bench.py needs an MI355X") >= 2, proc.stdout[-2000:]
+    # a launcher that starts the wrong number of ranks is refused
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True, env=env2, timeout=300)
+    assert proc.returncode != 0 and "WORLD_SIZE=4" in proc.stdout

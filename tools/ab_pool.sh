@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of the two SAH traversal forms (a ray per thread / refilled lane pool) on renders: tools/ab_pool.sh "<env settings>" ...
-run() { timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-exact --steps 1 --warmup 1 "$@" 2>/dev/null | python3 -c "
+run() { timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-exact --no-extend --steps 1 --warmup 1 "$@" 2>/dev/null | python3 -c "
 import json,sys
-r=json.loads(sys.stdin.readline()); o=r['roofline']['other']
-print('  ', r['config']['workload'].split(',')[0], '|', round(r['value'],1), 'Mpaths/s | extend_ms', o['extend_ms_total'] and round(o['extend_ms_total'],1), 'shade_ms', round(o['shade_ms_total'],1))"; }
+r=json.loads(sys.stdin.readline()); o=r['roofline']['stage_ms']
+print('  ', r['config']['workload'].split(',')[0], '|', round(r['value'],1), 'Mpaths/s | extend_ms', round(o['extend'],1), 'shade_ms', round(o['shade_or_pass_kernel'],1))"; }
 for cfg in "$@"; do
   echo "== $cfg"
   export $cfg

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Render throughput on the non-headline configurations (bench lines are the Cornell box only): C1 RTiOW,
 # C3 final scene / smoke, C4 one million spheres at reduced spp; the first three with the CPU oracle timed beside.
-run() { timeout -k 10 400 python3 bench.py --no-exact --steps 1 --warmup 1 "$@" | python3 -c "
+run() { timeout -k 10 400 python3 bench.py --no-exact --no-extend --steps 1 --warmup 1 "$@" | python3 -c "
 import json,sys
-r=json.loads(sys.stdin.readline()); o=r['roofline']['other']; c=r.get('cpu_baseline')
-print(r['config']['workload'], '|', round(r['value'],1), 'Mpaths/s | seg/path', round(r['config']['segments_per_path'],2), '| extend_ms', o['extend_ms_total'], 'shade_ms', o['shade_ms_total'], '| nan', r['config']['nan_pixel_fraction'],
+r=json.loads(sys.stdin.readline()); o=r['roofline']['stage_ms']; c=r.get('cpu_baseline')
+print(r['config']['workload'], '|', round(r['value'],1), 'Mpaths/s | seg/path', round(r['config']['segments_per_path'],2), '| extend_ms', o['extend'], 'shade_ms', o['shade_or_pass_kernel'], '| nan', r['config']['nan_pixel_fraction'],
       '| cpu', (str(round(c['value'],2))+' Mpaths/s on '+str(c['cores'])+' threads ('+c['sample']+'), gpu/cpu '+str(round(r['config']['gpu_over_cpu'],1))) if c else None)"; }
 run --scene random_scene --width 1200 --height 800 --spp 100 &&
 run --scene final_book_two --spp 256 &&

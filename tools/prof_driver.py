@@ -29,5 +29,5 @@ ctx.render(w, h, spp, depth)
 dt = time.perf_counter() - t0
 st = ctx.stats()
 print(f"{scene_name} {w}x{h}@{spp} depth {depth}: {dt * 1e3:.1f} ms, {w * h * spp / dt / 1e6:.1f} Mpaths/s, "
-      f"{st.segments / max(st.paths, 1):.3f} segments/path")
+      f"{st.segments / max(st.paths, 1):.3f} segments/path segments={int(st.segments)} paths={int(st.paths)}")
 ctx.close()
