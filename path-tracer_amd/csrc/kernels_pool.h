@@ -55,6 +55,9 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
     double time = 0.0;
     uint64_t pkey = 0;
     uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
+#ifdef PT_POOL_TIMING
+    long long tm_refill = 0, tm_walk = 0, tm_shade = 0, tm_rounds = 0, tm_lanes = 0, tm0 = clock64();
+#endif
     for (;;) {
         bool drained = false;
         for (;;) { // hand camera samples to free lanes
@@ -132,6 +135,9 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
         }
         if (drained) break; // nothing in flight, nothing left to start
         segments += (uint32_t)__popcll(__ballot(has));
+#ifdef PT_POOL_TIMING
+        { long long t = clock64(); tm_refill += t - tm0; tm0 = t; tm_rounds += 1; tm_lanes += __popcll(__ballot(has)); }
+#endif
         double ht;
         int32_t id;
         if constexpr (X) {
@@ -141,6 +147,9 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
         } else {
             extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along
         }
+#ifdef PT_POOL_TIMING
+        { long long t = clock64(); tm_walk += t - tm0; tm0 = t; }
+#endif
         if (has) {
             const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
             D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
@@ -162,7 +171,15 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
                 has = false;
             }
         }
+#ifdef PT_POOL_TIMING
+        { long long t = clock64(); tm_shade += t - tm0; tm0 = t; }
+#endif
     }
+#ifdef PT_POOL_TIMING
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("pool timing: rounds %lld lanes/round %.1f cycles/round refill %.0f walk %.0f shade %.0f\n", tm_rounds,
+               (double)tm_lanes / tm_rounds, (double)tm_refill / tm_rounds, (double)tm_walk / tm_rounds, (double)tm_shade / tm_rounds);
+#endif
     if (lane == 0 && segments) atomicAdd(&counts[0], segments); // the pass's segment count, for the statistics
 }
 

@@ -49,17 +49,36 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 double ni_over_nt, reflect_prob, cosine;
                 D3 refracted = d3(0.0, 0.0, 0.0);
                 const double d_dot_n = M<X>::dot(d, rec.n);
-                if (d_dot_n > 0.0) {
-                    outward_normal = -rec.n;
-                    ni_over_nt = lf.ref_idx;
-                    cosine = M<X>::div(lf.ref_idx * d_dot_n, M<X>::length(d));
+                if constexpr (X) {
+                    if (d_dot_n > 0.0) {
+                        outward_normal = -rec.n;
+                        ni_over_nt = lf.ref_idx;
+                        cosine = M<X>::div(lf.ref_idx * d_dot_n, M<X>::length(d));
+                    } else {
+                        outward_normal = rec.n;
+                        ni_over_nt = M<X>::rcp(lf.ref_idx);
+                        cosine = M<X>::div(-d_dot_n, M<X>::length(d));
+                    }
+                    if (refract<X>(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick<X>(cosine, lf.ref_idx);
+                    else reflect_prob = 1.0;
                 } else {
-                    outward_normal = rec.n;
-                    ni_over_nt = M<X>::rcp(lf.ref_idx);
-                    cosine = M<X>::div(-d_dot_n, M<X>::length(d));
+                    // the same with 1 / |d| formed once: the reference divides by |d| for the cosine and normalises d
+                    // again inside refract (src/material.rs:55,189,194)
+                    const bool outside = !(d_dot_n > 0.0);
+                    const double inv_len = fast_rsqrt(M<X>::squared_length(d));
+                    const double inv_idx = fast_rcp(lf.ref_idx);
+                    outward_normal = outside ? rec.n : -rec.n;
+                    ni_over_nt = outside ? inv_idx : lf.ref_idx;
+                    cosine = (outside ? -d_dot_n : lf.ref_idx * d_dot_n) * inv_len;
+                    const D3 uv = d * inv_len;
+                    const double dt = (outside ? d_dot_n : -d_dot_n) * inv_len; // uv . outward_normal
+                    const double discriminant = 1.0 - ni_over_nt * ni_over_nt * (1.0 - dt * dt);
+                    reflect_prob = 1.0;
+                    if (discriminant > 0.0) {
+                        refracted = ni_over_nt * (uv - outward_normal * dt) - outward_normal * fast_sqrt(discriminant);
+                        reflect_prob = schlick<X>(cosine, lf.ref_idx);
+                    }
                 }
-                if (refract<X>(d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick<X>(cosine, lf.ref_idx);
-                else reflect_prob = 1.0;
                 nd = (g.next() < reflect_prob) ? reflected : refracted;
                 no = rec.p;
                 nbeta = beta * d3(1.0, 1.0, 1.0); // specular: albedo * color(next), no emission (trace.rs:209-211)
@@ -84,8 +103,9 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
                 const D3 albedo = leaf_texture<TEX>(sv, lf, rec);
                 add_radiance(lx, ly, lz, pid, beta * emissive);
-                Onb uvw;
-                if (lambert) uvw = onb_from_w<X>(rec.n);
+                Onb uvw; // exact mode: the basis of CosinePDF::new(normal), src/material.rs:363-367
+                if constexpr (X)
+                    if (lambert) uvw = onb_from_w<X>(rec.n);
                 // MixturePDF::generate (src/material.rs:427-433), then HitableList::random (src/hitable.rs:74-77) or
                 // the material's own pdf. Every sampler a lane can end up in takes its next two draws (or none):
                 // their bits are made once, by all lanes together, before the lanes part ways.
@@ -94,8 +114,36 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 if (to_light) which = (int)((double)sv.n_lights * g.next());
                 const uint32_t u1 = g.peek_u32(1), u2 = g.peek_u32(2);
                 D3 dir;
-                if (to_light) dir = light_random<X>(sv.lights[which], u1, u2, g, rec.p);
-                else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(u1, u2, g)) : iso_dir;
+                if constexpr (X) {
+                    if (to_light) dir = light_random<X>(sv.lights[which], u1, u2, g, rec.p);
+                    else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(u1, u2, g)) : iso_dir;
+                } else {
+                    // The cone towards a sphere light (src/sphere.rs:16-25,96-101) and the cosine lobe about the normal
+                    // (src/material.rs:10-19) are the same construction: a basis about an axis, z from the second
+                    // draw, the azimuth from the first. The lanes of both run it together instead of one group after
+                    // the other; what differs is selected per lane.
+                    const DevLight &l = sv.lights[which];
+                    const bool to_sphere = to_light && l.kind == LIGHT_SPHERE;
+                    if (to_sphere || (!to_light && lambert)) {
+                        g.n += 2;
+                        const double r1 = bits_to_f64(u1), r2 = bits_to_f64(u2);
+                        const D3 axis = to_sphere ? d3(l.d[0], l.d[1], l.d[2]) - rec.p : rec.n;
+                        const double radius2 = l.d[3] * l.d[3];
+                        // sphere: cos_theta_max = sqrt(1 - r^2 / |axis|^2), z = 1 + r2 (cos_theta_max - 1); lobe: z = sqrt(1 - r2)
+                        const double q = to_sphere ? radius2 * weight_rcp(M<X>::squared_length(axis)) : r2;
+                        const double root = weight_sqrt(1.0 - q);
+                        const double z = to_sphere ? __builtin_fma(r2, root - 1.0, 1.0) : root;
+                        // sphere: sqrt(1 - z^2); lobe: sqrt(r2)
+                        const double planar = weight_sqrt(to_sphere ? __builtin_fma(-z, z, 1.0) : r2);
+                        double sn, cs;
+                        fast_sincos_2pi(r1, sn, cs);
+                        dir = onb_local(onb_from_w<X>(axis), d3(cs * planar, sn * planar, z));
+                    } else if (to_light) {
+                        dir = light_random<X>(l, u1, u2, g, rec.p); // rectangle, or a shape without random()
+                    } else {
+                        dir = iso_dir;
+                    }
+                }
                 // MixturePDF::value, src/material.rs:424-426
                 double len2 = 0.0, inv_len = 0.0;
                 D3 unit_dir;
@@ -107,7 +155,8 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 }
                 double own = iso_pdf;
                 if (lambert) { // CosinePDF::value, src/material.rs:375-382
-                    double cosine = M<X>::dot(unit_dir, uvw.w);
+                    // (fast mode: the basis' w is the unit normal itself up to its last bit)
+                    double cosine = X ? M<X>::dot(unit_dir, uvw.w) : M<X>::dot(unit_dir, rec.n);
                     own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
                 }
                 const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir, len2, inv_len) + 0.5 * own;
@@ -122,12 +171,11 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 if constexpr (!X) {
                     // A Lambertian direction below the surface has scattering_pdf 0: the reference goes on with a
                     // throughput of 0 * x / pdf = 0 (the mixture pdf is positive there: the direction came from a
-                    // light). Such a path can only add 0 * (finite radiance) from here on; without Isotropic
-                    // materials nothing downstream turns that into NaN, so fast mode stops it. The weight is pinned
-                    // to the 0 the reference gets, also where a reciprocal's rounding would make pdf_val 0.
-                    const bool below = lambert && spdf == 0.0; // a NaN spdf is not "below": it propagates
-                    if (below) nbeta = d3(0.0, 0.0, 0.0);
-                    dead = below && !sv.has_isotropic;
+                    // light). Such a path can only add 0 * (finite radiance) from here on; unless the scene has a
+                    // source of NaN weights (SceneView::zero_can_turn_nan) fast mode stops it. A NaN or zero pdf
+                    // makes the weight NaN, as it does in the reference, and the path goes on.
+                    const bool zero = nbeta.x == 0.0 && nbeta.y == 0.0 && nbeta.z == 0.0;
+                    dead = lambert && spdf == 0.0 && zero && !sv.zero_can_turn_nan;
                 }
                 no = rec.p;
                 done = false;

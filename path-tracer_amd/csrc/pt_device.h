@@ -260,7 +260,10 @@ struct SceneView {
     int32_t n_lights;
     int32_t has_medium;
     int32_t has_frames;
-    int32_t has_isotropic; // some material is Isotropic: throughput can turn NaN (0 * x / 0, src/trace.rs:217-220)
+    // A throughput of exactly 0 can still turn NaN further down the path (0 * x / 0 or 0 * NaN, src/trace.rs:217-220):
+    // some material is Isotropic, or a diffuse surface reaches into a sphere light shape, where Sphere::pdf_value is
+    // the square root of a negative number (src/sphere.rs:92-94). Fast mode then follows such paths to their end.
+    int32_t zero_can_turn_nan;
 };
 
 // ------------------------------------------------------------ transforms --
@@ -769,7 +772,7 @@ template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3
         D3 inv = d3(0.0, 0.0, 0.0);
         const double dk = l.axis == 0 ? direction.x : (l.axis == 1 ? direction.y : direction.z);
         if constexpr (!X) {
-            const double r = fast_rcp(dk);
+            const double r = weight_rcp(dk); // t only enters the pdf value
             inv = d3(r, r, r);
         }
         if (rect_t<X>(l.d[0], l.d[1], l.d[2], l.d[3], l.d[4], l.axis, origin, direction, inv, 0.001, kF64Max, t)) {

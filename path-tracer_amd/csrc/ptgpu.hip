@@ -821,9 +821,27 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     v.n_leaves = (int32_t)f.leaves.size();
     v.has_medium = f.has_medium ? 1 : 0;
     v.has_frames = f.has_frames ? 1 : 0;
-    v.has_isotropic = 0;
+    v.zero_can_turn_nan = 0;
     for (int i = 0; i < scene->n_materials; ++i)
-        if (scene->materials[i].kind == PT_M_ISOTROPIC) v.has_isotropic = 1;
+        if (scene->materials[i].kind == PT_M_ISOTROPIC) v.zero_can_turn_nan = 1;
+    // a Lambertian primitive whose bounds reach inside a sphere light shape: light pdfs from there are NaN
+    for (int32_t k = 0; k < f.n_traversal_ops && !v.zero_can_turn_nan; ++k) {
+        const DevOp &op = f.ops[k];
+        if (op.leaf < 0 || f.leaves[op.leaf].mat_kind != PT_M_LAMBERTIAN) continue;
+        double lo[3], hi[3];
+        if (!accel_prim_bounds(f, op, lo, hi)) continue;
+        for (const DevLight &l : f.lights) {
+            if (l.kind != LIGHT_SPHERE) continue;
+            double d2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double c = l.d[a], gap = c < lo[a] ? lo[a] - c : (c > hi[a] ? c - hi[a] : 0.0);
+                d2 += gap * gap;
+            }
+            // (the bounds carry the 1e-4 pad of src/rect.rs:116-122: a surface that merely touches the shape, as the
+            // Cornell floor touches the glass sphere's, does not count)
+            if (std::sqrt(d2) < l.d[3] - 1e-3) v.zero_can_turn_nan = 1;
+        }
+    }
     // texture level: what the leaves' materials still have to evaluate at a hit (constant colours are in the leaves)
     ctx->tex = 0;
     for (const DevLeaf &lf : f.leaves) {

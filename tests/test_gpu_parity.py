@@ -72,12 +72,12 @@ def test_render_parity_small(any_ctx, name, spp, depth):
     ref = ref[..., :3].astype(np.float64)
     nan_same = (np.isnan(got) == np.isnan(ref)).mean()
     finite = np.isfinite(got) & np.isfinite(ref)
-    # same RNG streams, f64 geometry: nearly every pixel follows the same paths as the oracle. Exact mode agrees
-    # to 1e-5 per channel; fast mode samples directions with f32 sin/cos, so its radiance differs by ~1e-6 relative
-    # per bounce and a few more paths flip a hit/miss decision.
-    close = np.isclose(got, ref, rtol=1e-5 if exact else 2e-3, atol=1e-7 if exact else 1e-5) | ~finite
-    assert nan_same >= 0.995, f"{name}: NaN masks agree on {nan_same:.4f}"
-    assert close.mean() >= (0.99 if exact else 0.97), f"{name}: {close.mean():.4f} of channels agree"
+    # same RNG streams, f64 arithmetic in both modes: nearly every pixel follows the same paths as the oracle and
+    # agrees to 1e-5 per channel; fast mode differs by a few ulp per operation, which only shows where it flips a
+    # hit / miss decision (and, in the final scene, a tie between coplanar box faces: tests/test_gpu_bench_forms.py)
+    close = np.isclose(got, ref, rtol=1e-5, atol=1e-7) | ~finite
+    assert nan_same >= (0.995 if exact or name != "final_book_two" else 0.99), f"{name}: NaN masks agree on {nan_same:.4f}"
+    assert close.mean() >= 0.99, f"{name}: {close.mean():.4f} of channels agree"
     rmse = np.sqrt(np.mean((got[finite] - ref[finite]) ** 2))
     scale = max(np.sqrt(np.mean(ref[finite] ** 2)), 1e-12)
     assert rmse / scale <= 0.05, f"{name}: relative RMSE {rmse / scale:.3e}"
@@ -124,8 +124,8 @@ def test_image_matches_committed_golden(any_ctx):
     ctx.upload(scene)
     ctx.render(32, 32, 8, 50)
     got = ctx.readback()[..., :3]
-    close = np.isclose(got, g["rgb"], rtol=1e-5 if exact else 2e-3, atol=1e-7 if exact else 1e-5)
-    assert close.mean() >= (0.99 if exact else 0.97)
+    close = np.isclose(got, g["rgb"], rtol=1e-5, atol=1e-7)
+    assert close.mean() >= 0.99
 
 
 def test_tile_renders_compose_to_the_full_image(gpu_ctx):
@@ -175,8 +175,8 @@ def test_realtime_mode_matches_oracle(any_ctx):
     touched = counts > 0
     assert 0.55 < touched.mean() < 0.9          # 1 - 0.8^6 = 0.74 of the pixels have been traced at least once
     assert (got[~touched][..., :3] == 0).all()
-    close = np.isclose(got[..., :3], ref[..., :3], rtol=1e-5 if exact else 2e-3, atol=1e-6 if exact else 1e-5)
-    assert close.mean() >= (0.99 if exact else 0.97)
+    close = np.isclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6)
+    assert close.mean() >= 0.99
 
 
 def test_error_codes(gpu_ctx):
@@ -302,8 +302,8 @@ def test_book_semantics_smoke_scene(any_ctx):
     ref = ref[..., :3].astype(np.float64)
     assert np.isfinite(ref).all() and np.isfinite(got).all()
     assert ref.mean() > 0.01  # the smoke volumes now carry light
-    close = np.isclose(got, ref, rtol=1e-5 if exact else 2e-3, atol=1e-7 if exact else 1e-5)
-    assert close.mean() >= (0.999 if exact else 0.97)
+    close = np.isclose(got, ref, rtol=1e-5, atol=1e-7)
+    assert close.mean() >= 0.999
     rmse = np.sqrt(np.mean((got - ref) ** 2)) / max(np.sqrt(np.mean(ref ** 2)), 1e-12)
     assert rmse <= (1e-6 if exact else 0.05)
     ctx.render(w, h, 8, 12)
