@@ -353,7 +353,9 @@ int pt_group_loopback(pt_ctx *ctx);
 typedef struct pt_scene pt_scene; /* owns the arrays a pt_scene_desc points into */
 
 /* Named scene recipes of the reference (src/lib.rs:674-1077) plus the synthetic sphere cloud.
- * `param` is recipe-specific (sphere count for "sphere_cloud", 1 = book semantics for "cornell_smoke"). */
+ * `param` is recipe-specific: the sphere count for "sphere_cloud"; 1 for "cornell_smoke" and "final_book_two" makes
+ * the light-shape list the scene's own light instead of the pair hard-coded in src/trace.rs:123-128 (and, for the
+ * smoke box, flips the light towards the room): with PT_RENDER_BOOK_SEMANTICS that gives a finite image. */
 int pt_scene_build_named(const char *name, double aspect, uint64_t seed, int64_t param,
                          pt_scene **out, pt_camera *camera_out);
 /* Replaces the decode step of ImageTexture::new(EARTH_TEXTURE_BYTES) (src/texture.rs:84-98, src/lib.rs:767): the crate

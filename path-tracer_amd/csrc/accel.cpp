@@ -347,6 +347,24 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
         // self-contained: the op applies the full world -> primitive chain itself (no ENTER / EXIT frames here)
         op.kind = op_pack(op_kind(op.kind), op_axis(op.kind), lf.full_count);
         op.chain_start = lf.full_start;
+        if (op_kind(op.kind) == OP_SPHERE && lf.full_count > 0) {
+            // A sphere under translations and rotations is a sphere: its centre is carried out to world space once,
+            // here, and the traversal tests it against the world ray with no chain at all (the hit distance along
+            // the ray is the same in both frames; the hit record is still built in the primitive's frame).
+            double c[3] = {op.d[0], op.d[1], op.d[2]};
+            for (int k = lf.full_count - 1; k >= 0; --k) {
+                const DevXform &x = flat.xforms[(size_t)lf.full_start + k];
+                const double wx = x.c * c[0] + x.s * c[2], wz = -x.s * c[0] + x.c * c[2]; // hitable.rs:189-194
+                c[0] = wx + x.tx;
+                c[1] = c[1] + x.ty;
+                c[2] = wz + x.tz;
+            }
+            op.d[0] = c[0];
+            op.d[1] = c[1];
+            op.d[2] = c[2];
+            op.kind = op_pack(OP_SPHERE, 0, 0);
+            op.chain_start = 0;
+        }
         out.prims.push_back(op);
     }
     return true;

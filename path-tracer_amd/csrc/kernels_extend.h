@@ -273,36 +273,6 @@ __device__ __forceinline__ bool sphere_pred(D3 c, double radius, D3 o, D3 d, dou
     which = ok0 ? 0 : 1;
     return (disc > 0.0) & (ok0 | ok1);
 }
-// AxisAlignedBox::hit (src/axis_aligned_box.rs:17-40): six rectangle tests with a shrinking t_max find the nearer
-// of the (at most two) faces the ray crosses inside [t_min, t_max]. The slab form finds the same pair directly:
-// entry = latest near plane, exit = earliest far plane; the face is the plane that set it. Ties go to X, then Y,
-// then Z, as the reference's face order (+Z -Z +Y -Y +X -X, later face wins an equal t) gives.
-__device__ __forceinline__ bool box_pred(const double *pb, D3 o, D3 inv, double t_min, double t_max, double &t,
-                                         int &face) {
-    const double x0 = (pb[0] - o.x) * inv.x, x1 = (pb[3] - o.x) * inv.x;
-    const double y0 = (pb[1] - o.y) * inv.y, y1 = (pb[4] - o.y) * inv.y;
-    const double z0 = (pb[2] - o.z) * inv.z, z1 = (pb[5] - o.z) * inv.z;
-    const double nx = fmin(x0, x1), fx = fmax(x0, x1);
-    const double ny = fmin(y0, y1), fy = fmax(y0, y1);
-    const double nz = fmin(z0, z1), fz = fmax(z0, z1);
-    const double tn = fmax(nx, fmax(ny, nz)), tf = fmin(fx, fmin(fy, fz));
-    const bool entry = !(tn < t_min);
-    t = entry ? tn : tf;
-    const int axis_n = (nx == tn) ? 0 : ((ny == tn) ? 1 : 2);
-    const int axis_f = (fx == tf) ? 0 : ((fy == tf) ? 1 : 2);
-    const int axis = entry ? axis_n : axis_f;
-    const double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
-    // entering through the max plane means travelling in -axis; leaving through it, in +axis
-    const bool max_plane = entry ? (ia < 0.0) : (ia > 0.0);
-    face = (2 - axis) * 2 + (max_plane ? 0 : 1);
-    // A rectangle accepts t == t_max (src/rect.rs:99), but a box is reached through the BVH node that holds it,
-    // whose bounds are exactly the box, and AABB::hit rejects an interval that has shrunk to a point
-    // (`tmax <= tmin`, src/math/aabb.rs:41): a box ENTERED exactly at the current closest distance is never
-    // tested. That is what decides coplanar pairs such as a box standing on a floor seen from below.
-    const bool in_range = entry ? (t < t_max) : !(t > t_max);
-    return (tn <= tf) & !(t < t_min) & in_range;
-}
-
 // Closest hit over the fused kernels' op list (see pt_scene_upload): no BOX ops, and a primitive's transform chain
 // is spelled out as XFORM ops in front of it. Every lane of the wave tests every primitive, in stream order. Op
 // records come through the scalar cache, one iteration ahead of their use, so a wave never waits for the record it

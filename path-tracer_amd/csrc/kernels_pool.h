@@ -180,7 +180,9 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
         printf("pool timing: rounds %lld lanes/round %.1f cycles/round refill %.0f walk %.0f shade %.0f\n", tm_rounds,
                (double)tm_lanes / tm_rounds, (double)tm_refill / tm_rounds, (double)tm_walk / tm_rounds, (double)tm_shade / tm_rounds);
 #endif
-    if (lane == 0 && segments) atomicAdd(&counts[0], segments); // the pass's segment count, for the statistics
+    // the pass's segment count, for the statistics: 32-bit partial sums spread over the shard slots of bounce row 0
+    // (the readers add the slots up in 64 bits), so that the total may pass 2^32
+    if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
 #define PT_TREE_UV_WAVES 2 // waves per SIMD of the textured variants: their shading is the largest code here (4: 638, 3: 640, 2: 730 Mpaths/s on the final scene)
 #endif
 template <int TEX, bool MEDIA>
-__global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
+__global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk) {
@@ -212,6 +214,12 @@ __global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) vo
     uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
     int32_t best = -1, node = kDone;
     int sp = 0;
+#ifdef PT_POOL_TIMING
+    long long tm_refill = 0, tm_inner = 0, tm_leaf = 0, tm_shade = 0, tm_rounds = 0, tm_shades = 0, tm_lanes = 0, tm0 = clock64();
+#define PT_TICK(acc) { long long t_ = clock64(); acc += t_ - tm0; tm0 = t_; }
+#else
+#define PT_TICK(acc)
+#endif
     auto start_ray = [&]() { // (o, d) hold a new ray
         inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
         closest = kF64Max;
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) vo
                 break; // nothing in flight, nothing left to start
             }
         }
+        PT_TICK(tm_refill)
         // traversal: inner nodes for as long as at least `inner_min` lanes are on one, then the leaves
         for (;;) {
             if (has && node >= 0) {
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) vo
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(has && node >= 0));
             if (n_inner == 0 || n_inner < inner_min) break;
         }
+        PT_TICK(tm_inner)
         if (has && node < 0 && node != kDone) {
             const int32_t ref = ~node;
             const int32_t first = ref >> 3, count = ref & 7;
@@ -306,10 +316,15 @@ __global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) vo
             }
             node = sp ? stack[--sp][threadIdx.x] : kDone;
         }
+        PT_TICK(tm_leaf)
         // vertices: when enough lanes wait with a finished traversal, or too few are still traversing to go on
         const bool ready = has && node == kDone;
         const uint32_t n_ready = (uint32_t)__popcll(__ballot(ready));
         const uint32_t n_trav = (uint32_t)__popcll(__ballot(has && node != kDone));
+#ifdef PT_POOL_TIMING
+        tm_rounds += 1;
+        if (n_ready && (n_ready >= shade_min || n_trav <= trav_min)) { tm_shades += 1; tm_lanes += n_ready; }
+#endif
         if (n_ready && (n_ready >= shade_min || n_trav <= trav_min)) {
             segments += n_ready;
             if (ready) {
@@ -334,6 +349,13 @@ __global__ __launch_bounds__(kBlock, TEX ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) vo
                 }
             }
         }
+        PT_TICK(tm_shade)
     }
-    if (lane == 0 && segments) atomicAdd(&counts[0], segments);
+#ifdef PT_POOL_TIMING
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("tree pool timing: rounds %lld shade rounds %lld lanes/shade %.1f cycles/round refill %.0f inner %.0f leaf %.0f shade %.0f (per shade round %.0f)\n",
+               tm_rounds, tm_shades, (double)tm_lanes / (double)(tm_shades ? tm_shades : 1), (double)tm_refill / tm_rounds, (double)tm_inner / tm_rounds,
+               (double)tm_leaf / tm_rounds, (double)tm_shade / tm_rounds, (double)tm_shade / (double)(tm_shades ? tm_shades : 1));
+#endif
+    if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments); // as in k_path_pool
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
     } else {
         Rng g{pkey, rn};
         const HitRec rec = finalize_hit<X, TEX>(sv, lf, o, d, time, ht, (id >> 28) & 7);
-        const D3 emissive = emitted<TEX>(sv, lf, d, rec);
+        const D3 emissive = emitted<X, TEX>(sv, lf, d, rec);
         bool done = true, dead = false;
         if (depth < max_depth) {
             if (lf.mat_kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
@@ -101,7 +101,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     if (book) iso_dir = sample;
                 }
                 const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
-                const D3 albedo = leaf_texture<TEX>(sv, lf, rec);
+                const D3 albedo = leaf_texture<X, TEX>(sv, lf, rec);
                 add_radiance(lx, ly, lz, pid, beta * emissive);
                 Onb uvw; // exact mode: the basis of CosinePDF::new(normal), src/material.rs:363-367
                 if constexpr (X)

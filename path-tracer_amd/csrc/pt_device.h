@@ -433,6 +433,36 @@ PT_DEV bool box_t(const double *pb, D3 o, D3 d, D3 inv, double t_min, double t_m
     return any;
 }
 
+// AxisAlignedBox::hit (src/axis_aligned_box.rs:17-40): six rectangle tests with a shrinking t_max find the nearer
+// of the (at most two) faces the ray crosses inside [t_min, t_max]. The slab form finds the same pair directly:
+// entry = latest near plane, exit = earliest far plane; the face is the plane that set it. Ties go to X, then Y,
+// then Z, as the reference's face order (+Z -Z +Y -Y +X -X, later face wins an equal t) gives.
+PT_DEV bool box_pred(const double *pb, D3 o, D3 inv, double t_min, double t_max, double &t,
+                                         int &face) {
+    const double x0 = (pb[0] - o.x) * inv.x, x1 = (pb[3] - o.x) * inv.x;
+    const double y0 = (pb[1] - o.y) * inv.y, y1 = (pb[4] - o.y) * inv.y;
+    const double z0 = (pb[2] - o.z) * inv.z, z1 = (pb[5] - o.z) * inv.z;
+    const double nx = fmin(x0, x1), fx = fmax(x0, x1);
+    const double ny = fmin(y0, y1), fy = fmax(y0, y1);
+    const double nz = fmin(z0, z1), fz = fmax(z0, z1);
+    const double tn = fmax(nx, fmax(ny, nz)), tf = fmin(fx, fmin(fy, fz));
+    const bool entry = !(tn < t_min);
+    t = entry ? tn : tf;
+    const int axis_n = (nx == tn) ? 0 : ((ny == tn) ? 1 : 2);
+    const int axis_f = (fx == tf) ? 0 : ((fy == tf) ? 1 : 2);
+    const int axis = entry ? axis_n : axis_f;
+    const double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
+    // entering through the max plane means travelling in -axis; leaving through it, in +axis
+    const bool max_plane = entry ? (ia < 0.0) : (ia > 0.0);
+    face = (2 - axis) * 2 + (max_plane ? 0 : 1);
+    // A rectangle accepts t == t_max (src/rect.rs:99), but a box is reached through the BVH node that holds it,
+    // whose bounds are exactly the box, and AABB::hit rejects an interval that has shrunk to a point
+    // (`tmax <= tmin`, src/math/aabb.rs:41): a box ENTERED exactly at the current closest distance is never
+    // tested. That is what decides coplanar pairs such as a box standing on a floor seen from below.
+    const bool in_range = entry ? (t < t_max) : !(t > t_max);
+    return (tn <= tf) & !(t < t_min) & in_range;
+}
+
 template <bool X> PT_DEV D3 moving_center(const double *pd, const double *e, double time) { // src/sphere.rs:130-132
     return d3(pd[0], pd[1], pd[2]) + M<X>::div(time - pd[4], pd[5]) * d3(e[0], e[1], e[2]);
 }
@@ -455,7 +485,8 @@ PT_DEV bool prim_hit_framed(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3
         return rect_t<X>(op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], (op.kind >> 8) & 3, o, d, inv, t_min, t_max,
                          t_out);
     case OP_BOXPRIM:
-        return box_t<X>(op.d, o, d, inv, t_min, t_max, t_out, sub);
+        if constexpr (X) return box_t<X>(op.d, o, d, inv, t_min, t_max, t_out, sub);
+        else return box_pred(op.d, o, inv, t_min, t_max, t_out, sub); // fast mode: the slab form of the same test
     default:
         return false;
     }
@@ -479,7 +510,8 @@ PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, d
         return rect_t<X>(op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], (op.kind >> 8) & 3, o, d, inv, t_min, t_max,
                          t_out);
     case OP_BOXPRIM:
-        return box_t<X>(op.d, o, d, inv, t_min, t_max, t_out, sub);
+        if constexpr (X) return box_t<X>(op.d, o, d, inv, t_min, t_max, t_out, sub);
+        else return box_pred(op.d, o, inv, t_min, t_max, t_out, sub); // fast mode: the slab form of the same test
     default:
         return false;
     }
@@ -629,19 +661,37 @@ PT_DEV double clamp_ref(double a, double lo, double hi) { // src/math/mod.rs:22-
 // Texture::value (src/texture.rs:24-28, 47-56, 70-75, 101-114). Checker children are resolved iteratively.
 // TEX is the scene's texture level, a property of the uploaded scene that the kernels are specialised on:
 //   0  every material's texture is a constant colour (already copied into the leaf records: nothing to evaluate);
-//   1  checker / noise textures occur (functions of the hit point);
-//   2  image textures occur too (functions of the surface u, v).
+//   1  checker textures over constant colours occur (three sines of the hit point);
+//   2  noise or image textures occur too (Perlin turbulence; the surface u, v of the hit).
 // The Perlin evaluation alone is several thousand instructions and some forty registers; a kernel for a scene without
 // it must not carry it.
-template <int TEX> PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) {
+// CheckerTexture::value picks `odd` when sin(10 x) sin(10 y) sin(10 z) < 0 (src/texture.rs:49-54). Only the sign of
+// the product is used, and the sign of sin(y) is the parity of floor(y / pi): fast mode takes the three parities
+// instead of three general-argument sines (a few hundred instructions each). A factor that is exactly zero makes the
+// product zero, i.e. not negative.
+template <bool X> PT_DEV bool checker_is_odd(D3 p) {
+    if constexpr (X) {
+        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+        return sines < 0.0;
+    } else {
+        const double ax = 10.0 * p.x, ay = 10.0 * p.y, az = 10.0 * p.z;
+        const double kx = floor(ax * kFrac1Pi), ky = floor(ay * kFrac1Pi), kz = floor(az * kFrac1Pi);
+        // parity of k: k - 2 floor(k / 2) is 0 or 1, exactly, for every finite k
+        const double odd = (kx - 2.0 * floor(0.5 * kx)) + (ky - 2.0 * floor(0.5 * ky)) + (kz - 2.0 * floor(0.5 * kz));
+        const bool any_zero = (ax == 0.0) | (ay == 0.0) | (az == 0.0);
+        return (odd == 1.0 || odd == 3.0) && !any_zero;
+    }
+}
+template <bool X, int TEX> PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) {
     if constexpr (TEX == 0) return d3(0.0, 0.0, 0.0);
     const pt_texture *t = &sv.textures[tex];
-    for (int guard = 0; guard < 16 && t->kind == PT_T_CHECKER; ++guard) {
-        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
-        t = &sv.textures[sines < 0.0 ? t->odd : t->even];
+    if (t->kind == PT_T_CHECKER) { // the cell is the same at every level of nested checkers
+        const bool odd = checker_is_odd<X>(p);
+#pragma unroll 1
+        for (int guard = 0; guard < 16 && t->kind == PT_T_CHECKER; ++guard) t = &sv.textures[odd ? t->odd : t->even];
     }
     if (t->kind == PT_T_CONSTANT) return d3(t->colour[0], t->colour[1], t->colour[2]);
-    if (t->kind == PT_T_NOISE) {
+    if (TEX == 2 && t->kind == PT_T_NOISE) {
         double noise = t->scale * p.z + 10.0 * perlin_turb(sv.perlin, p, 7);
         double g = 1.0 * 0.5 * (1.0 + sin(noise));
         return d3(g, g, g);
@@ -843,18 +893,18 @@ template <bool X> PT_DEV double schlick(double cosine, double ref_idx) { // src/
 }
 
 // The material's texture at a hit: the colour inlined in the leaf record, or the general evaluator.
-template <int TEX> PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec) {
+template <bool X, int TEX> PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec) {
     if (TEX == 0 || lf.texture < 0) return d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
-    return texture_value<TEX>(sv, lf.texture, rec.u, rec.v, rec.p);
+    return texture_value<X, TEX>(sv, lf.texture, rec.u, rec.v, rec.p);
 }
 // Material::emitted (src/material.rs:145-147 default, 303-305 Lambertian, 325-331 DiffuseLight).
-template <int TEX> PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec) {
+template <bool X, int TEX> PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec) {
     if (lf.mat_kind == PT_M_LAMBERTIAN) {
-        if (lf.emissive > 0.0) return leaf_texture<TEX>(sv, lf, rec) * lf.emissive;
+        if (lf.emissive > 0.0) return leaf_texture<X, TEX>(sv, lf, rec) * lf.emissive;
         return d3(0.0, 0.0, 0.0);
     }
     if (lf.mat_kind == PT_M_DIFFUSE_LIGHT) {
-        if (dot(rec.n, ray_d) < 0.0) return leaf_texture<TEX>(sv, lf, rec);
+        if (dot(rec.n, ray_d) < 0.0) return leaf_texture<X, TEX>(sv, lf, rec);
         return d3(0.0, 0.0, 0.0);
     }
     return d3(0.0, 0.0, 0.0);

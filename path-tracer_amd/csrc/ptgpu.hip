@@ -102,7 +102,7 @@ struct pt_ctx {
     bool have_scene = false, have_camera = false;
     FlatScene flat;
     SceneView view{};
-    int tex = 0; // texture level of the uploaded scene: 0 constant colours only, 1 checker / noise, 2 image textures too
+    int tex = 0; // texture level of the uploaded scene: 0 constant colours only, 1 checkers too, 2 noise / image textures too
     void *d_ops = nullptr, *d_xforms = nullptr, *d_leaves = nullptr, *d_lights = nullptr, *d_materials = nullptr,
          *d_textures = nullptr, *d_texels = nullptr, *d_perlin = nullptr;
     CameraDev cam{};
@@ -131,7 +131,8 @@ struct pt_ctx {
     std::vector<hipEvent_t> events;
     uint32_t profile_period = 8;
     uint64_t pass_counter = 0;
-    std::vector<uint32_t> h_counts, h_shard_counts;
+    std::vector<uint64_t> h_counts; // per bounce, summed over the shards
+    std::vector<uint32_t> h_shard_counts;
 
     // launch shaping
     bool exact = false;            // PT_CFG_EXACT
@@ -169,7 +170,7 @@ struct pt_ctx {
     int32_t n_accel_prims = 0;
     void *d_ops_fused = nullptr;
     int32_t n_fused_ops = 0;
-    std::vector<uint32_t> profile; // queue sizes per bounce of the last pass that was read back
+    std::vector<uint64_t> profile; // queue sizes per bounce of the last pass that was read back
     uint32_t profile_n = 0;        // its path count
 
     // Kept between calls and grown on demand, so that a loop of pt_intersect / pt_tonemap_device /
@@ -506,7 +507,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     }
     if (tree) {
         const uint32_t tiles = (n + 63u) / 64u;
-        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
+        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
         const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
@@ -849,7 +850,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
         std::vector<int> todo{lf.texture}; // a checker's children count too
         for (size_t k = 0; k < todo.size() && k < 64; ++k) {
             const pt_texture &t = scene->textures[todo[k]];
-            if (t.kind == PT_T_IMAGE) ctx->tex = 2;
+            if (t.kind == PT_T_IMAGE || t.kind == PT_T_NOISE) ctx->tex = 2;
             else if (t.kind != PT_T_CONSTANT) ctx->tex = std::max(ctx->tex, 1);
             if (t.kind == PT_T_CHECKER) {
                 todo.push_back(t.even);
