@@ -56,6 +56,7 @@ static_assert(sizeof(DevXform) == 48, "DevXform must be 48 bytes");
 // Everything shading a hit needs, in one record, so that a hit id leads to a single dependent fetch:
 // the primitive's geometry (a copy of its op), its wrapper chain and its material with constant textures
 // already resolved to a colour.
+constexpr int32_t kLeafTexUv = 1, kLeafTexNoise = 2;
 struct DevLeaf { // 192 bytes
     int32_t kind;        // OpKind of the geometry
     int32_t axis;
@@ -66,7 +67,8 @@ struct DevLeaf { // 192 bytes
     int32_t material;    // material index, reported in pt_hit
     int32_t op;          // op holding the geometry in the traversal stream
     int32_t prim[6];     // graph node reported as pt_hit.prim ([0] unless BOXPRIM, where it is per face)
-    int32_t pad[2];
+    int32_t tex_flags;   // kLeafTexUv: the texture reads the surface (u, v); kLeafTexNoise: it is a NOISE texture itself
+    int32_t pad;
     double g[6];         // geometry parameters (same as DevOp::d)
     double e[3];         // MSPHERE: center_range
     double albedo[3];    // constant texture colour (LAMBERTIAN / DIFFUSE_LIGHT / ISOTROPIC) or METAL albedo

@@ -388,6 +388,7 @@ int flatten_scene(const pt_scene_desc *scene, FlatScene &out, std::string &error
         if (lf.op >= 0 && lf.op < (int32_t)out.ops.size())
             for (int k = 0; k < 6; ++k) lf.g[k] = out.ops[lf.op].d[k];
         lf.texture = -1;
+        lf.tex_flags = 0;
         lf.mat_kind = PT_M_DUMMY;
         if (lf.material < 0 || lf.material >= scene->n_materials) continue;
         const pt_material &m = scene->materials[lf.material];
@@ -400,6 +401,17 @@ int flatten_scene(const pt_scene_desc *scene, FlatScene &out, std::string &error
             const pt_texture &t = scene->textures[m.texture];
             if (t.kind == PT_T_CONSTANT) for (int k = 0; k < 3; ++k) lf.albedo[k] = t.colour[k];
             else lf.texture = m.texture;
+            if (t.kind == PT_T_NOISE) lf.tex_flags |= kLeafTexNoise;
+            // an image texture, directly or under checkers, is what reads the surface (u, v)
+            std::vector<int> todo{m.texture};
+            for (size_t k = 0; k < todo.size() && k < 64; ++k) {
+                const pt_texture &c = scene->textures[todo[k]];
+                if (c.kind == PT_T_IMAGE) lf.tex_flags |= kLeafTexUv;
+                if (c.kind == PT_T_CHECKER) {
+                    if (c.even >= 0 && c.even < scene->n_textures) todo.push_back(c.even);
+                    if (c.odd >= 0 && c.odd < scene->n_textures) todo.push_back(c.odd);
+                }
+            }
         }
     }
     return PT_OK;

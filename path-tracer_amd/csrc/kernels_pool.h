@@ -28,10 +28,14 @@ struct PoolLds {
 #ifndef PT_EXACT_POOL_WAVES
 #define PT_EXACT_POOL_WAVES 3 // measured on the Cornell box: 1 -> 895, 2 -> 1506, 3 -> 1786, 4 -> 1704 Mpaths/s
 #endif
+#ifndef PT_MEDIA_POOL_WAVES
+#define PT_MEDIA_POOL_WAVES 3 // the variant with media inside (FUSE == 2): at 4 waves per SIMD it holds 196 B of scratch per lane (smoke box: 1 570 -> 2 220 Mpaths/s)
+#endif
+constexpr int pool_waves(bool exact, int fuse) { return exact ? PT_EXACT_POOL_WAVES : (fuse == 2 ? PT_MEDIA_POOL_WAVES : PT_SHADE_WAVES); }
 // X: exact mode. The walk is the wave-uniform scan of the reference's own threaded tree (every box test, the
 // reference's order), the arithmetic is M<true>'s; sv.ops is then the full stream, not the fused list.
 template <int TEX, int FUSE, bool X = false>
-__global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
+__global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
                                                                       uint32_t max_depth, double *lx, double *ly,
                                                                       double *lz, uint32_t *counts, uint32_t flags,
                                                                       uint32_t refill_arg, uint32_t chunk) {
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
     uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
 #ifdef PT_POOL_TIMING
     long long tm_refill = 0, tm_walk = 0, tm_shade = 0, tm_rounds = 0, tm_lanes = 0, tm0 = clock64();
+    for (int k = lane; k < 3 * kShadePhases + 1; k += 64) shade_clock()[k] = 0;
 #endif
     for (;;) {
         bool drained = false;
@@ -176,9 +181,14 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
 #endif
     }
 #ifdef PT_POOL_TIMING
-    if (blockIdx.x == 7 && threadIdx.x == 0)
+    if (blockIdx.x == 7 && threadIdx.x == 0) {
         printf("pool timing: rounds %lld lanes/round %.1f cycles/round refill %.0f walk %.0f shade %.0f\n", tm_rounds,
                (double)tm_lanes / tm_rounds, (double)tm_refill / tm_rounds, (double)tm_walk / tm_rounds, (double)tm_shade / tm_rounds);
+        const long long *c = shade_clock();
+        for (int k = 0; k < kShadePhases; ++k)
+            printf("  vertex phase %2d: cycles/round %7.0f  executed in %.3f of rounds  lanes when executed %.1f\n", k,
+                   (double)c[3 * k] / tm_rounds, (double)c[3 * k + 1] / tm_rounds, (double)c[3 * k + 2] / (double)(c[3 * k + 1] ? c[3 * k + 1] : 1));
+    }
 #endif
     // the pass's segment count, for the statistics: 32-bit partial sums spread over the shard slots of bounce row 0
     // (the readers add the slots up in 64 bits), so that the total may pass 2^32
@@ -195,6 +205,13 @@ __global__ __launch_bounds__(kBlock, X ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) v
 #ifndef PT_TREE_UV_WAVES
 #define PT_TREE_UV_WAVES 2 // waves per SIMD of the textured variants: their shading is the largest code here (4: 638, 3: 640, 2: 730 Mpaths/s on the final scene)
 #endif
+// LDS of the variants for scenes with noise / image textures: the Perlin tables and the scratch of wave_turb7
+template <int TEX> struct TreePoolTexLds {};
+template <> struct TreePoolTexLds<2> {
+    pt_perlin perlin;
+    double ps[kWavesPerBlock][64][3];
+    double rs[kWavesPerBlock][9][8];
+};
 template <int TEX, bool MEDIA>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
@@ -205,6 +222,14 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
                    trav_min = tuning >> 24;
     constexpr int32_t kDone = INT32_MIN; // never a leaf reference
     const uint32_t lane = threadIdx.x & 63u;
+    __shared__ TreePoolTexLds<TEX> T;
+    if constexpr (TEX == 2) {
+        if (sv.perlin) {
+            const uint32_t *src = (const uint32_t *)sv.perlin;
+            for (uint32_t k = threadIdx.x; k < sizeof(pt_perlin) / 4u; k += kBlock) ((uint32_t *)&T.perlin)[k] = src[k];
+        }
+        __syncthreads(); // the only barrier of the kernel
+    }
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
     bool has = false;
@@ -217,6 +242,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
 #ifdef PT_POOL_TIMING
     long long tm_refill = 0, tm_inner = 0, tm_leaf = 0, tm_shade = 0, tm_rounds = 0, tm_shades = 0, tm_lanes = 0, tm0 = clock64();
 #define PT_TICK(acc) { long long t_ = clock64(); acc += t_ - tm0; tm0 = t_; }
+    for (int k = lane; k < 3 * kShadePhases + 1; k += 64) shade_clock()[k] = 0;
 #else
 #define PT_TICK(acc)
 #endif
@@ -327,12 +353,23 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
 #endif
         if (n_ready && (n_ready >= shade_min || n_trav <= trav_min)) {
             segments += n_ready;
+            const int32_t li = best < 0 ? 0 : (best & 0x0fffffff);
+            double turbulence = 0.0;
+            bool noise_hit = false;
+            if constexpr (TEX == 2) { // hits on noise-textured leaves: the wave evaluates their turbulence together
+                noise_hit = ready && best >= 0 && (sv.leaves[li].tex_flags & kLeafTexNoise) != 0;
+                if (__ballot(noise_hit)) {
+                    D3 p = o;
+                    if (noise_hit) p = finalize_hit<false, TEX>(sv, sv.leaves[li], o, d, time, closest, (best >> 28) & 7).p;
+                    const uint32_t wv = threadIdx.x >> 6;
+                    turbulence = wave_turb7(&T.perlin, T.ps[wv], T.rs[wv], noise_hit, p);
+                }
+            }
             if (ready) {
-                const int32_t li = best < 0 ? 0 : (best & 0x0fffffff);
                 D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
                 const bool alive = shade_vertex<false, TEX, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
                                                                             closest, best, depth, max_depth, flags, lx, ly,
-                                                                            lz, no, nd, nbeta, &c);
+                                                                            lz, no, nd, nbeta, &c, noise_hit ? &turbulence : nullptr);
                 if (depth == 0) sum = c; // the per-path sum of the other forms
                 else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
                 if (alive) {
@@ -356,6 +393,12 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
         printf("tree pool timing: rounds %lld shade rounds %lld lanes/shade %.1f cycles/round refill %.0f inner %.0f leaf %.0f shade %.0f (per shade round %.0f)\n",
                tm_rounds, tm_shades, (double)tm_lanes / (double)(tm_shades ? tm_shades : 1), (double)tm_refill / tm_rounds, (double)tm_inner / tm_rounds,
                (double)tm_leaf / tm_rounds, (double)tm_shade / tm_rounds, (double)tm_shade / (double)(tm_shades ? tm_shades : 1));
+    if (blockIdx.x == 7 && threadIdx.x == 0) {
+        const long long *c = shade_clock();
+        for (int k = 0; k < kShadePhases; ++k)
+            printf("  vertex phase %2d: cycles/shade round %7.0f  executed in %.3f of shade rounds  lanes when executed %.1f\n", k,
+                   (double)c[3 * k] / tm_shades, (double)c[3 * k + 1] / tm_shades, (double)c[3 * k + 2] / (double)(c[3 * k + 1] ? c[3 * k + 1] : 1));
+    }
 #endif
     if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments); // as in k_path_pool
 }

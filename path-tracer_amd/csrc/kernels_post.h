@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, Scen
             h.material = -1;
         } else {
             const DevLeaf lf = sv.leaves[id & 0x0fffffff];
-            const HitRec rec = finalize_hit<X, 2>(sv, lf, d3(q.ox(i), q.oy(i), q.oz(i)),
+            const HitRec rec = finalize_hit<X, 3>(sv, lf, d3(q.ox(i), q.oy(i), q.oz(i)),
                                                      d3(q.dx(i), q.dy(i), q.dz(i)), q.tm(i), hit_t[i], (id >> 28) & 7);
             h.t = rec.t; h.u = rec.u; h.v = rec.v;
             h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;

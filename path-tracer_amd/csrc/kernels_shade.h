@@ -16,10 +16,32 @@ __device__ __forceinline__ void add_radiance(double *lx, double *ly, double *lz,
     }
 }
 
+#ifdef PT_POOL_TIMING
+// Diagnostic build: cycles, executions and active lanes of the parts of a vertex, per wave, kept in LDS (every active
+// lane stores the same value). Phase 0 closes at the call's entry, so it holds the time between vertices.
+constexpr int kShadePhases = 12;
+__device__ __forceinline__ long long *shade_clock() {
+    __shared__ long long clk[kWavesPerBlock][3 * kShadePhases + 1];
+    return clk[threadIdx.x >> 6];
+}
+#define PT_SHADE_TICK(k)                                                        \
+    {                                                                           \
+        long long *c_ = shade_clock();                                          \
+        const long long t_ = clock64();                                         \
+        c_[3 * (k)] += t_ - c_[3 * kShadePhases];                               \
+        c_[3 * (k) + 1] += 1;                                                   \
+        c_[3 * (k) + 2] += __popcll(__ballot(true));                            \
+        c_[3 * kShadePhases] = t_;                                              \
+    }
+#else
+#define PT_SHADE_TICK(k)
+#endif
+
 // One path vertex: the body of `color` (src/trace.rs:198-234) for a ray whose closest hit is (ht, id), id < 0 for a
 // miss. `lf` is the hit primitive's leaf record (fields are fetched where they are used; any record when id < 0).
 // Adds the vertex's radiance to the path's accumulator and, if the path goes on, returns true with the next ray,
 // throughput and RNG draw count.
+// `turbulence`: the Perlin turbulence at this hit when the caller has evaluated it already (wave_turb7), else null.
 // RAD_RETURN: the vertex's radiance (every branch adds at most once) is handed back in `vertex_radiance` and nothing
 // is written (the caller keeps the path's sum).
 enum RadianceMode { RAD_ADD = 0, RAD_RETURN = 2 };
@@ -27,20 +49,24 @@ template <bool X, int TEX, int FIRST = RAD_ADD>
 __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, D3 beta,
                                              uint64_t pkey, uint32_t pid, uint32_t &rn, double ht, int32_t id,
                                              uint32_t depth, uint32_t max_depth, uint32_t flags, double *lx, double *ly,
-                                             double *lz, D3 &no, D3 &nd, D3 &nbeta, D3 *vertex_radiance = nullptr) {
+                                             double *lz, D3 &no, D3 &nd, D3 &nbeta, D3 *vertex_radiance = nullptr,
+                                             const double *turbulence = nullptr) {
     bool alive = false;
     D3 first = d3(0.0, 0.0, 0.0);
     auto add_radiance = [&](double *ax, double *ay, double *az, uint32_t path, D3 c) {
         if constexpr (FIRST != RAD_ADD) first = c;
         else ::add_radiance(ax, ay, az, path, c);
     };
+    PT_SHADE_TICK(0)
     if (id < 0) {
         // miss: colour is black (src/trace.rs:227); the product still carries a NaN throughput through
         add_radiance(lx, ly, lz, pid, beta * 0.0);
     } else {
         Rng g{pkey, rn};
         const HitRec rec = finalize_hit<X, TEX>(sv, lf, o, d, time, ht, (id >> 28) & 7);
-        const D3 emissive = emitted<X, TEX>(sv, lf, d, rec);
+        PT_SHADE_TICK(1)
+        const D3 emissive = emitted<X, TEX>(sv, lf, d, rec, turbulence);
+        PT_SHADE_TICK(2)
         bool done = true, dead = false;
         if (depth < max_depth) {
             if (lf.mat_kind == PT_M_DIELECTRIC) { // src/material.rs:177-212
@@ -83,12 +109,14 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 no = rec.p;
                 nbeta = beta * d3(1.0, 1.0, 1.0); // specular: albedo * color(next), no emission (trace.rs:209-211)
                 done = false;
+                PT_SHADE_TICK(3)
             } else if (lf.mat_kind == PT_M_METAL) { // src/material.rs:230-241
                 D3 reflected = reflect<X>(M<X>::unit_vector(d), rec.n);
                 nd = reflected + lf.fuzz * random_in_unit_sphere(g);
                 no = rec.p;
                 nbeta = beta * d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
                 done = false;
+                PT_SHADE_TICK(4)
             } else if (lf.mat_kind == PT_M_LAMBERTIAN || lf.mat_kind == PT_M_ISOTROPIC) {
                 const bool lambert = lf.mat_kind == PT_M_LAMBERTIAN;
                 // scatter(): src/material.rs:289-301 (Lambertian), 347-351 (Isotropic draws a sphere sample it never uses)
@@ -101,7 +129,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     if (book) iso_dir = sample;
                 }
                 const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;
-                const D3 albedo = leaf_texture<X, TEX>(sv, lf, rec);
+                const D3 albedo = leaf_texture<X, TEX>(sv, lf, rec, turbulence);
                 add_radiance(lx, ly, lz, pid, beta * emissive);
                 Onb uvw; // exact mode: the basis of CosinePDF::new(normal), src/material.rs:363-367
                 if constexpr (X)
@@ -114,6 +142,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 if (to_light) which = (int)((double)sv.n_lights * g.next());
                 const uint32_t u1 = g.peek_u32(1), u2 = g.peek_u32(2);
                 D3 dir;
+                PT_SHADE_TICK(5)
                 if constexpr (X) {
                     if (to_light) dir = light_random<X>(sv.lights[which], u1, u2, g, rec.p);
                     else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(u1, u2, g)) : iso_dir;
@@ -138,12 +167,15 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                         double sn, cs;
                         fast_sincos_2pi(r1, sn, cs);
                         dir = onb_local(onb_from_w<X>(axis), d3(cs * planar, sn * planar, z));
+                        PT_SHADE_TICK(6)
                     } else if (to_light) {
                         dir = light_random<X>(l, u1, u2, g, rec.p); // rectangle, or a shape without random()
+                        PT_SHADE_TICK(7)
                     } else {
                         dir = iso_dir;
                     }
                 }
+                PT_SHADE_TICK(8)
                 // MixturePDF::value, src/material.rs:424-426
                 double len2 = 0.0, inv_len = 0.0;
                 D3 unit_dir;
@@ -159,7 +191,9 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     double cosine = X ? M<X>::dot(unit_dir, uvw.w) : M<X>::dot(unit_dir, rec.n);
                     own = cosine > 0.0 ? cosine * kFrac1Pi : 0.0;
                 }
+                PT_SHADE_TICK(9)
                 const double pdf_val = 0.5 * lights_pdf_value<X>(sv, rec.p, dir, len2, inv_len) + 0.5 * own;
+                PT_SHADE_TICK(10)
                 double spdf = iso_pdf;
                 if (lambert) { // Lambertian::scattering_pdf, src/material.rs:268-275
                     double cosine = M<X>::dot(rec.n, unit_dir);
@@ -179,6 +213,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 }
                 no = rec.p;
                 done = false;
+                PT_SHADE_TICK(11)
             }
         }
         if (done) add_radiance(lx, ly, lz, pid, beta * emissive); // src/trace.rs:225

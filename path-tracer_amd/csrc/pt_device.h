@@ -563,9 +563,12 @@ PT_DEV void get_sphere_uv(D3 p, double &u, double &v) { // src/sphere.rs:8-14
 // Rebuilds the HitRecord of the closest hit from (world ray, t, leaf, sub): the leaf's full chain takes the
 // ray to the primitive's space with the same sequence of operations the traversal used, the record is built
 // there as the primitive's hit() does, then carried back out through the wrappers in reverse.
-// TEX: what the scene's textures need (see texture_value); surface (u, v) are only computed for TEX == 2.
+// TEX: what the scene's textures need (see texture_value). The surface (u, v) feed image textures and nothing else
+// (a sphere's take an atan2 and an asin): TEX == 2 computes them for the leaves whose texture reads them, TEX == 3
+// (the hit records pt_intersect returns) for every leaf, lower levels never.
 template <bool X, int TEX>
 PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, double t, int sub) {
+    const bool want_uv = TEX == 3 || (TEX == 2 && (lf.tex_flags & kLeafTexUv) != 0);
     apply_chain<X>(sv.xforms, lf.full_start, lf.full_count, o, d);
     HitRec r;
     r.t = t;
@@ -578,14 +581,14 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, d
     r.p = point;
     if (lf.kind == OP_SPHERE) {
         D3 c = d3(g[0], g[1], g[2]);
-        if (TEX == 2) {
+        if (want_uv) {
             if (sub == 0) get_sphere_uv(M<X>::divs(c - point, g[3]), r.u, r.v); // sphere.rs:56
             else get_sphere_uv(c - point, r.u, r.v);                               // sphere.rs:69
         }
         r.n = M<X>::divs(point - c, g[3]);
     } else if (lf.kind == OP_MSPHERE) {
         D3 c = moving_center<X>(g, lf.e, time);
-        if (TEX == 2) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
+        if (want_uv) get_sphere_uv(c - point, r.u, r.v); // sphere.rs:150,163
         r.n = M<X>::divs(point - c, g[3]);
     } else if (lf.kind == OP_RECT || lf.kind == OP_BOXPRIM) {
         double amin, amax, bmin, bmax, c;
@@ -597,7 +600,7 @@ PT_DEV HitRec finalize_hit(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, d
             box_face(g, sub, amin, amax, bmin, bmax, c, axis);
             r.prim = lf.prim[sub];
         }
-        if (TEX == 2) {
+        if (want_uv) {
             double a, b;
             if (axis == 0) { a = M<X>::mad(t, d.y, o.y); b = M<X>::mad(t, d.z, o.z); }
             else if (axis == 1) { a = M<X>::mad(t, d.x, o.x); b = M<X>::mad(t, d.z, o.z); }
@@ -653,6 +656,47 @@ PT_DEV double perlin_turb(const pt_perlin *t, D3 p, int depth) { // src/math/noi
     }
     return fabs(accum);
 }
+// perlin_turb(p, 7) for the lanes of a wave that `want` it, evaluated by the whole wave: lane 7 s + i computes octave i
+// (the noise at 2^i p, weighted 2^-i; both scalings are exact) for the s-th wanting lane of a batch of nine, and each
+// wanting lane then adds its seven terms in the order of the serial loop, so the value has the bits perlin_turb gives.
+// An octave is two dependent table reads behind some forty instructions; one lane walking seven of them in a row,
+// with the other lanes of the wave idle, is what a noise-textured hit used to cost. `tab` may live in LDS. `ps` (64
+// points) and `rs` (nine rows of eight) are scratch of the calling wave alone. Must be called by all 64 lanes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_turb7(const pt_perlin *tab, double (*ps)[3], double (*rs)[8], bool want, D3 p) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long mask = __ballot(want);
+    const uint32_t total = (uint32_t)__popcll(mask);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (want) {
+        ps[rank][0] = p.x;
+        ps[rank][1] = p.y;
+        ps[rank][2] = p.z;
+    }
+    wave_lds_fence();
+    const uint32_t slot = lane / 7u, oct = lane - slot * 7u;
+    double result = 0.0;
+    for (uint32_t base = 0; base < total; base += 9u) { // wave-uniform trip count
+        const uint32_t k = base + slot;
+        if (lane < 63u && k < total) {
+            const double s = (double)(1u << oct), w = 1.0 / s;
+            rs[slot][oct] = w * perlin_noise(tab, d3(ps[k][0] * s, ps[k][1] * s, ps[k][2] * s));
+        }
+        wave_lds_fence();
+        if (want && rank >= base && rank < base + 9u) {
+            double accum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) accum += rs[rank - base][i];
+            result = fabs(accum);
+        }
+        wave_lds_fence();
+    }
+    return result;
+}
 PT_DEV double clamp_ref(double a, double lo, double hi) { // src/math/mod.rs:22-26
     double b = a > hi ? hi : a;
     b = b < lo ? lo : b;
@@ -682,7 +726,9 @@ template <bool X> PT_DEV bool checker_is_odd(D3 p) {
         return (odd == 1.0 || odd == 3.0) && !any_zero;
     }
 }
-template <bool X, int TEX> PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p) {
+// `turbulence`: perlin_turb(p, 7) already evaluated for this hit (by the whole wave, see wave_turb7), or null.
+template <bool X, int TEX>
+PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p, const double *turbulence = nullptr) {
     if constexpr (TEX == 0) return d3(0.0, 0.0, 0.0);
     const pt_texture *t = &sv.textures[tex];
     if (t->kind == PT_T_CHECKER) { // the cell is the same at every level of nested checkers
@@ -692,7 +738,7 @@ template <bool X, int TEX> PT_DEV D3 texture_value(const SceneView &sv, int tex,
     }
     if (t->kind == PT_T_CONSTANT) return d3(t->colour[0], t->colour[1], t->colour[2]);
     if (TEX == 2 && t->kind == PT_T_NOISE) {
-        double noise = t->scale * p.z + 10.0 * perlin_turb(sv.perlin, p, 7);
+        double noise = t->scale * p.z + 10.0 * (turbulence ? *turbulence : perlin_turb(sv.perlin, p, 7));
         double g = 1.0 * 0.5 * (1.0 + sin(noise));
         return d3(g, g, g);
     }
@@ -893,18 +939,20 @@ template <bool X> PT_DEV double schlick(double cosine, double ref_idx) { // src/
 }
 
 // The material's texture at a hit: the colour inlined in the leaf record, or the general evaluator.
-template <bool X, int TEX> PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec) {
+template <bool X, int TEX>
+PT_DEV D3 leaf_texture(const SceneView &sv, const DevLeaf &lf, const HitRec &rec, const double *turbulence = nullptr) {
     if (TEX == 0 || lf.texture < 0) return d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
-    return texture_value<X, TEX>(sv, lf.texture, rec.u, rec.v, rec.p);
+    return texture_value<X, TEX>(sv, lf.texture, rec.u, rec.v, rec.p, turbulence);
 }
 // Material::emitted (src/material.rs:145-147 default, 303-305 Lambertian, 325-331 DiffuseLight).
-template <bool X, int TEX> PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec) {
+template <bool X, int TEX>
+PT_DEV D3 emitted(const SceneView &sv, const DevLeaf &lf, D3 ray_d, const HitRec &rec, const double *turbulence = nullptr) {
     if (lf.mat_kind == PT_M_LAMBERTIAN) {
-        if (lf.emissive > 0.0) return leaf_texture<X, TEX>(sv, lf, rec) * lf.emissive;
+        if (lf.emissive > 0.0) return leaf_texture<X, TEX>(sv, lf, rec, turbulence) * lf.emissive;
         return d3(0.0, 0.0, 0.0);
     }
     if (lf.mat_kind == PT_M_DIFFUSE_LIGHT) {
-        if (dot(rec.n, ray_d) < 0.0) return leaf_texture<X, TEX>(sv, lf, rec);
+        if (dot(rec.n, ray_d) < 0.0) return leaf_texture<X, TEX>(sv, lf, rec, turbulence);
         return d3(0.0, 0.0, 0.0);
     }
     return d3(0.0, 0.0, 0.0);

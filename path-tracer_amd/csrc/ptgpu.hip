@@ -476,7 +476,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     }
     if (pool || xpool) {
         const uint32_t tiles = (n + 63u) / 64u;
-        const uint32_t resident = (uint32_t)ctx->n_cu * (xpool ? PT_EXACT_POOL_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
+        const bool media = ctx->view.has_medium != 0;
+        const uint32_t resident = (uint32_t)ctx->n_cu * pool_waves(xpool, media ? 2 : 1) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         // a small pass is cut into at least four chunks per wave so that the waves finish together
         const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
@@ -487,7 +488,6 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
-        const bool media = ctx->view.has_medium != 0;
         HIP_TRY(ctx, send_pool_consts());
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, (const PoolConsts *)ctx->d_pool_consts, n,

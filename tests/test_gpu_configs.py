@@ -201,24 +201,29 @@ def test_tree_traversal_forms_agree(name, param):
     assert (base[0]["prim"] >= 0).mean() > 0.1
 
 
-@pytest.mark.parametrize("name,param", [("random_scene", 0), ("final_book_two", 0), ("sphere_cloud", 50000)])
-def test_tree_pool_gives_the_same_image(name, param):
+@pytest.mark.parametrize("name,param,rflags", [("random_scene", 0, 0), ("final_book_two", 0, 0),
+                                               ("final_book_two", 1, ptgpu.PT_RENDER_BOOK_SEMANTICS), ("sphere_cloud", 50000, 0)])
+def test_tree_pool_gives_the_same_image(name, param, rflags):
     """Scenes traced through the SAH tree: an offline pass run as one launch whose lanes carry a path each (traversal
     and shading interleaved inside the wave) against ray generation plus an extend and a shade launch per bounce.
-    Same paths, same arithmetic per path: bit-identical images and segment counts, whatever the thresholds."""
+    Same paths, same arithmetic per path: bit-identical images and segment counts, whatever the thresholds. The final
+    scene with its own light and book semantics has finite pixels all over its noise-textured sphere, whose turbulence
+    the one-launch form evaluates with the lanes of a wave working together and the other form lane by lane."""
     scene = ptgpu.Scene.named(name, 4 / 3, param=param)
     w, h, spp = 160, 120, 6
 
     def run(**tuning):
         ctx = _ctx(max_paths_in_flight=1 << 16, **tuning)
         ctx.upload(scene)
-        ctx.render(w, h, spp, 50)
+        ctx.render(w, h, spp, 50, flags=rflags)
         img, st = ctx.readback(), ctx.stats()
         ctx.close()
         return img, st
 
     a, st_a = run(pass_form=ptgpu.PT_PASS_PER_BOUNCE)
     assert st_a.launches_extend > 0
+    if rflags:
+        assert np.isfinite(a[..., :3]).mean() > 0.99
     for tuning in ({}, {"tree_refill": 1, "tree_inner": 1, "tree_shade": 1, "tree_trav_plus1": 1},
                    {"tree_refill": 64, "tree_inner": 64, "tree_shade": 64, "tree_trav_plus1": 64, "pool_chunk": 64}):
         b, st_b = run(**tuning)
