@@ -850,6 +850,8 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
         std::vector<int> todo{lf.texture}; // a checker's children count too
         for (size_t k = 0; k < todo.size() && k < 64; ++k) {
             const pt_texture &t = scene->textures[todo[k]];
+            if (t.kind == PT_T_NOISE && !scene->perlin)
+                return set_error(ctx, PT_ERR_INVALID_ARG, "a NOISE texture needs pt_scene_desc.perlin");
             if (t.kind == PT_T_IMAGE || t.kind == PT_T_NOISE) ctx->tex = 2;
             else if (t.kind != PT_T_CONSTANT) ctx->tex = std::max(ctx->tex, 1);
             if (t.kind == PT_T_CHECKER) {
