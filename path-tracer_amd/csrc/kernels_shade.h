@@ -158,15 +158,17 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                         const double r1 = bits_to_f64(u1), r2 = bits_to_f64(u2);
                         const D3 axis = to_sphere ? d3(l.d[0], l.d[1], l.d[2]) - rec.p : rec.n;
                         const double radius2 = l.d[3] * l.d[3];
+                        // 1 / |axis| serves twice: squared, for the cone's opening, and as the basis' normalisation
+                        const double inv_axis = weight_rsqrt(M<X>::squared_length(axis));
                         // sphere: cos_theta_max = sqrt(1 - r^2 / |axis|^2), z = 1 + r2 (cos_theta_max - 1); lobe: z = sqrt(1 - r2)
-                        const double q = to_sphere ? radius2 * weight_rcp(M<X>::squared_length(axis)) : r2;
+                        const double q = to_sphere ? radius2 * (inv_axis * inv_axis) : r2;
                         const double root = weight_sqrt(1.0 - q);
                         const double z = to_sphere ? __builtin_fma(r2, root - 1.0, 1.0) : root;
                         // sphere: sqrt(1 - z^2); lobe: sqrt(r2)
                         const double planar = weight_sqrt(to_sphere ? __builtin_fma(-z, z, 1.0) : r2);
                         double sn, cs;
                         fast_sincos_2pi(r1, sn, cs);
-                        dir = onb_local(onb_from_w<X>(axis), d3(cs * planar, sn * planar, z));
+                        dir = onb_local_fma(onb_from_w_scaled(axis, inv_axis), d3(cs * planar, sn * planar, z));
                         PT_SHADE_TICK(6)
                     } else if (to_light) {
                         dir = light_random<X>(l, u1, u2, g, rec.p); // rectangle, or a shape without random()

@@ -451,16 +451,21 @@ PT_DEV bool box_pred(const double *pb, D3 o, D3 inv, double t_min, double t_max,
     const int axis_n = (nx == tn) ? 0 : ((ny == tn) ? 1 : 2);
     const int axis_f = (fx == tf) ? 0 : ((fy == tf) ? 1 : 2);
     const int axis = entry ? axis_n : axis_f;
-    const double ia = axis == 0 ? inv.x : (axis == 1 ? inv.y : inv.z);
-    // entering through the max plane means travelling in -axis; leaving through it, in +axis
-    const bool max_plane = entry ? (ia < 0.0) : (ia > 0.0);
-    face = (2 - axis) * 2 + (max_plane ? 0 : 1);
+    // Entering through the max plane means travelling in -axis; leaving through it, in +axis: the max plane is hit
+    // when (travelling in -axis) == entry. The direction of travel is the sign bit of 1 / d (an infinity keeps the
+    // sign of its zero). Faces are numbered +Z -Z +Y -Y +X -X.
+    const uint32_t negative = ((uint32_t)__double2hiint(inv.x) >> 31) | (((uint32_t)__double2hiint(inv.y) >> 31) << 1) |
+                              (((uint32_t)__double2hiint(inv.z) >> 31) << 2);
+    const uint32_t min_plane = ((negative >> axis) & 1u) ^ (entry ? 1u : 0u);
+    face = 4 - 2 * axis + (int)min_plane;
     // A rectangle accepts t == t_max (src/rect.rs:99), but a box is reached through the BVH node that holds it,
     // whose bounds are exactly the box, and AABB::hit rejects an interval that has shrunk to a point
     // (`tmax <= tmin`, src/math/aabb.rs:41): a box ENTERED exactly at the current closest distance is never
     // tested. That is what decides coplanar pairs such as a box standing on a floor seen from below.
-    const bool in_range = entry ? (t < t_max) : !(t > t_max);
-    return (tn <= tf) & !(t < t_min) & in_range;
+    // (entry: t = tn and tn >= t_min holds already; exit: t = tf must not lie below t_min nor beyond t_max)
+    const bool ok_entry = entry & (tn < t_max);
+    const bool ok_exit = !entry & !(tf < t_min) & !(tf > t_max);
+    return (tn <= tf) & (ok_entry | ok_exit);
 }
 
 template <bool X> PT_DEV D3 moving_center(const double *pd, const double *e, double time) { // src/sphere.rs:130-132
@@ -529,8 +534,28 @@ PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv,
     const DevOp &bop = sv.ops[op.skip];
     double t1, t2;
     int sub;
-    if (!prim_hit<X>(sv, bop, o, d, inv, time, -kF64Max, kF64Max, t1, sub)) return false;
-    if (!prim_hit<X>(sv, bop, o, d, inv, time, t1 + 0.0001, kF64Max, t2, sub)) return false;
+    if (!X && (bop.kind & 0xff) == OP_SPHERE && ((bop.kind >> 16) & 0xff) == 0) {
+        // A sphere boundary without a chain of its own: both calls of Sphere::hit below evaluate the same two roots
+        // (src/sphere.rs:44-81). The first, over (-MAX, MAX), takes the near root r0 (whenever it is finite); the
+        // second, over (r0 + 0.0001, MAX), can then only take the far root. Same expressions as sphere_t<false>, once.
+        const D3 oc = o - d3(bop.d[0], bop.d[1], bop.d[2]);
+        const double a = M<X>::dot(d, d), b = M<X>::dot(oc, d);
+        const double c = __builtin_fma(-bop.d[3], bop.d[3], M<X>::dot(oc, oc));
+        const double discriminant = __builtin_fma(-a, c, b * b);
+        if (!(discriminant > 0.0)) return false;
+        const double root = M<X>::sqrt_(discriminant), inv_a = fast_rcp(a);
+        const double r0 = (-b - root) * inv_a, r1 = (-b + root) * inv_a;
+        if (r0 < kF64Max && r0 > -kF64Max) {
+            t1 = r0;
+            if (!(r1 < kF64Max && r1 > t1 + 0.0001)) return false;
+            t2 = r1;
+        } else {
+            return false; // r0 not finite: the first call would take r1 and the second find nothing beyond it
+        }
+    } else {
+        if (!prim_hit<X>(sv, bop, o, d, inv, time, -kF64Max, kF64Max, t1, sub)) return false;
+        if (!prim_hit<X>(sv, bop, o, d, inv, time, t1 + 0.0001, kF64Max, t2, sub)) return false;
+    }
     t1 = fmax(t1, t_min);
     t2 = fmin(t2, t_max);
     if (t1 >= t2) return false;
@@ -760,6 +785,21 @@ PT_DEV bool texture_is_constant(const SceneView &sv, int tex) { return sv.textur
 struct Onb { // src/onb.rs:18-37
     D3 u, v, w;
 };
+// a x b with each component as one multiply and one FMA (fast mode)
+PT_DEV D3 cross_fma(D3 a, D3 b) {
+    return D3{__builtin_fma(a.y, b.z, -(a.z * b.y)), -__builtin_fma(a.x, b.z, -(a.z * b.x)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
+}
+// Fast mode's basis about n, with 1 / |n| from the caller: the same basis as the exact form's, the products by the
+// zeros and ones of `a` written out: w x (0,1,0) = (-w.z, 0, w.x), w x (1,0,0) = (0, w.z, -w.y)
+PT_DEV Onb onb_from_w_scaled(D3 n, double inv_len) {
+    const D3 w = n * inv_len;
+    const bool big = fabs(w.x) > 0.9;
+    const double p = big ? w.x : w.y;
+    const double r = weight_rsqrt(__builtin_fma(w.z, w.z, p * p));
+    const D3 v = big ? d3(-w.z * r, 0.0, w.x * r) : d3(0.0, w.z * r, -w.y * r);
+    const D3 u = cross_fma(w, v);
+    return Onb{u, v, w};
+}
 template <bool X> PT_DEV Onb onb_from_w(D3 n) {
     if constexpr (X) {
         D3 w = M<X>::unit_vector(n);
@@ -768,18 +808,15 @@ template <bool X> PT_DEV Onb onb_from_w(D3 n) {
         D3 u = cross(w, v);
         return Onb{u, v, w};
     } else {
-        // the same basis with the products by the zeros and ones of `a` written out: w x (0,1,0) = (-w.z, 0, w.x),
-        // w x (1,0,0) = (0, w.z, -w.y)
-        const D3 w = n * weight_rsqrt(M<X>::squared_length(n));
-        const bool big = fabs(w.x) > 0.9;
-        const double p = big ? w.x : w.y;
-        const double r = weight_rsqrt(__builtin_fma(w.z, w.z, p * p));
-        const D3 v = big ? d3(-w.z * r, 0.0, w.x * r) : d3(0.0, w.z * r, -w.y * r);
-        const D3 u = cross(w, v);
-        return Onb{u, v, w};
+        return onb_from_w_scaled(n, weight_rsqrt(M<X>::squared_length(n)));
     }
 }
 PT_DEV D3 onb_local(const Onb &b, D3 a) { return b.u * a.x + b.v * a.y + b.w * a.z; }
+PT_DEV D3 onb_local_fma(const Onb &b, D3 a) { // the same sums with fused multiply-adds (fast mode)
+    return D3{__builtin_fma(b.w.x, a.z, __builtin_fma(b.v.x, a.y, b.u.x * a.x)),
+              __builtin_fma(b.w.y, a.z, __builtin_fma(b.v.y, a.y, b.u.y * a.x)),
+              __builtin_fma(b.w.z, a.z, __builtin_fma(b.v.z, a.y, b.u.z * a.x))};
+}
 
 // The direction samplers below take the raw bits u1, u2 of the NEXT two draws of `g` (Rng::peek_u32), which the
 // caller computes once for every lane of the wave, whichever sampler a lane ends up in: the integer hashing then runs
@@ -841,6 +878,7 @@ template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3
     if (l.kind == LIGHT_SPHERE) {
         D3 c = d3(l.d[0], l.d[1], l.d[2]);
         bool hit;
+        double dist2 = 0.0;
         if constexpr (X) {
             double t;
             int which;
@@ -851,13 +889,15 @@ template <bool X> PT_DEV double light_pdf_value(const DevLight &l, D3 origin, D3
             // y < 0, else disc > y^2. No square root, no quotient.
             const D3 oc = origin - c;
             const double b = M<X>::dot(oc, direction);
-            const double cc = __builtin_fma(-l.d[3], l.d[3], M<X>::dot(oc, oc));
+            dist2 = M<X>::dot(oc, oc); // = |c - origin|^2, bit for bit
+            const double cc = __builtin_fma(-l.d[3], l.d[3], dist2);
             const double disc = __builtin_fma(-len2, cc, b * b);
             const double y = __builtin_fma(0.001, len2, b);
             hit = (disc > 0.0) & ((y < 0.0) | (disc > y * y));
         }
         if (hit) {
-            double cos_theta_max = W<X>::sqrt_(1.0 - W<X>::div(l.d[3] * l.d[3], M<X>::squared_length(c - origin)));
+            if constexpr (X) dist2 = M<X>::squared_length(c - origin);
+            double cos_theta_max = W<X>::sqrt_(1.0 - W<X>::div(l.d[3] * l.d[3], dist2));
             double solid_angle = 2.0 * kPi * (1.0 - cos_theta_max);
             return W<X>::rcp(solid_angle);
         }
