@@ -203,7 +203,9 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
 // together and start their next ray; free lanes take new camera samples from the pass's chunk counter.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef PT_TREE_UV_WAVES
-#define PT_TREE_UV_WAVES 2 // waves per SIMD of the textured variants: their shading is the largest code here (4: 638, 3: 640, 2: 730 Mpaths/s on the final scene)
+#define PT_TREE_UV_WAVES 3 // waves per SIMD of the variants for noise / image textures, the largest code here. Final scene, Mpaths/s: with the
+                           // turbulence evaluated per lane 4: 638, 3: 640, 2: 730; with the wave evaluating it together 2: 994 / 756,
+                           // 3: 1 015 / 828 (reference / book semantics); four 45-KiB workgroups do not fit a CU's LDS
 #endif
 // LDS of the variants for scenes with noise / image textures: the Perlin tables and the scratch of wave_turb7
 template <int TEX> struct TreePoolTexLds {};
