@@ -399,6 +399,38 @@ __device__ __forceinline__ bool accel_box(const float *lo, const float *hi, D3 o
     return tn <= tf;
 }
 
+// The slab tests of a 32-byte node (AccelNodeQ). A plane is gmin + q cell, so its distance along the ray is
+// (gmin + q cell - o) inv = q (cell inv) + (gmin - o) inv: one FMA per plane with two per-ray constants per axis.
+// 1 / d is clamped to +-1e300 for them: along an axis the ray runs parallel to, an infinite factor would turn every
+// product into NaN (0 inf, inf - inf), which min / max drop, and such a ray would then be culled by nothing on that
+// axis (a ray with a zero direction by nothing at all); with the clamp the distances are +-huge with the right sign.
+struct QuantRay {
+    D3 a, b;
+};
+__device__ __forceinline__ QuantRay quant_ray(const AccelGrid &g, D3 o, D3 inv) {
+    const double big = 1.0e300;
+    const D3 i = d3(fmin(fmax(inv.x, -big), big), fmin(fmax(inv.y, -big), big), fmin(fmax(inv.z, -big), big));
+    return QuantRay{d3(g.cell[0] * i.x, g.cell[1] * i.y, g.cell[2] * i.z),
+                    d3((g.gmin[0] - o.x) * i.x, (g.gmin[1] - o.y) * i.y, (g.gmin[2] - o.z) * i.z)};
+}
+__device__ __forceinline__ void accel_boxes_q(const AccelNodeQ &n, const QuantRay &r, double t_min, double t_max, bool &h0,
+                                              bool &h1, double &t0, double &t1) {
+#define PT_Q(v, s, A, B) __builtin_fma((double)(uint32_t)(v)[s], A, B)
+    const double x00 = PT_Q(n.lo[0], 0, r.a.x, r.b.x), x01 = PT_Q(n.hi[0], 0, r.a.x, r.b.x);
+    const double y00 = PT_Q(n.lo[1], 0, r.a.y, r.b.y), y01 = PT_Q(n.hi[1], 0, r.a.y, r.b.y);
+    const double z00 = PT_Q(n.lo[2], 0, r.a.z, r.b.z), z01 = PT_Q(n.hi[2], 0, r.a.z, r.b.z);
+    const double x10 = PT_Q(n.lo[0], 1, r.a.x, r.b.x), x11 = PT_Q(n.hi[0], 1, r.a.x, r.b.x);
+    const double y10 = PT_Q(n.lo[1], 1, r.a.y, r.b.y), y11 = PT_Q(n.hi[1], 1, r.a.y, r.b.y);
+    const double z10 = PT_Q(n.lo[2], 1, r.a.z, r.b.z), z11 = PT_Q(n.hi[2], 1, r.a.z, r.b.z);
+#undef PT_Q
+    t0 = fmax(fmax(fmin(x00, x01), fmin(y00, y01)), fmax(fmin(z00, z01), t_min));
+    t1 = fmax(fmax(fmin(x10, x11), fmin(y10, y11)), fmax(fmin(z10, z11), t_min));
+    const double f0 = fmin(fmin(fmax(x00, x01), fmax(y00, y01)), fmin(fmax(z00, z01), t_max));
+    const double f1 = fmin(fmin(fmax(x10, x11), fmax(y10, y11)), fmin(fmax(z10, z11), t_max));
+    h0 = t0 <= f0;
+    h1 = t1 <= f1;
+}
+
 template <bool MEDIA>
 __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q, SceneView sv, const AccelNode *nodes,
                                                          const DevOp *prims, ExtendArgs a) {
@@ -488,10 +520,12 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q,
 // (ballot + prefix count, no atomics: the run belongs to this wave alone). Each round first steps every lane down
 // through inner nodes until it stands on a leaf (or is done), then tests the leaves, so both loops run with most
 // lanes active. Runs are dealt shard by shard; any grid is correct.
-template <bool MEDIA>
+// QUANT: the nodes are read in their 32-byte form (`nodes_q`, `grid`); same hits.
+template <bool MEDIA, bool QUANT = false>
 __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Queue q, SceneView sv, const AccelNode *nodes,
                                                                             const DevOp *prims, ExtendArgs a,
-                                                                            uint32_t tuning) {
+                                                                            uint32_t tuning, const AccelNodeQ *nodes_q = nullptr,
+                                                                            AccelGrid grid = AccelGrid{}) {
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
     const uint32_t refill_at = tuning & 0xffu, inner_min = tuning >> 8;
     constexpr int32_t kDone = INT32_MIN;             // never a leaf reference (those are ~((first << 3) | count))
@@ -505,6 +539,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
     bool has = false;                    // this lane holds a ray in flight
     uint32_t my_i = 0;
     D3 o = d3(0, 0, 0), d = o, inv = o;
+    QuantRay qr{o, o};
     double time = 0.0, closest = 0.0;
     uint64_t pkey = 0;
     int32_t best = -1, node = kDone;
@@ -534,6 +569,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
                     time = q.tm(my_i);
                     if (MEDIA) pkey = (a.key_mode == 0) ? q.key(my_i) : intersect_key(a.medium_seed, my_i);
                     inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+                    if constexpr (QUANT) qr = quant_ray(grid, o, inv);
                     closest = a.t_max;
                     best = -1;
                     sp = 0;
@@ -549,11 +585,21 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
         // `inner_min` lanes are still on inner nodes
         for (;;) {
             if (has && node >= 0) {
-                const AccelNode &n = nodes[node];
                 double t0, t1;
-                const bool h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
-                const bool h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
-                const int32_t c0 = n.child[0], c1 = n.child[1];
+                bool h0, h1;
+                int32_t c0, c1;
+                if constexpr (QUANT) {
+                    const AccelNodeQ n = nodes_q[node];
+                    accel_boxes_q(n, qr, a.t_min, closest, h0, h1, t0, t1);
+                    c0 = n.child[0];
+                    c1 = n.child[1];
+                } else {
+                    const AccelNode &n = nodes[node];
+                    h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
+                    h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
+                    c0 = n.child[0];
+                    c1 = n.child[1];
+                }
                 if (h0 && h1) {
                     const bool first0 = t0 <= t1;
                     stack[sp++][threadIdx.x] = first0 ? c1 : c0;

@@ -135,6 +135,26 @@ __global__ __launch_bounds__(kBlock) void k_accel_refit_level(AccelNode *nodes, 
     }
 }
 
+// The 32-byte form of every node (accel.h), made from the f32 nodes wherever those came from (host build, refit,
+// device build). One step of slack on each side covers the rounding of the decode (gmin + steps * cell in f64).
+__global__ __launch_bounds__(kBlock) void k_accel_quantise(const AccelNode *nodes, AccelNodeQ *out, int32_t n, AccelGrid g) {
+    for (int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x); i < n; i += (int32_t)(gridDim.x * kBlock)) {
+        const AccelNode nd = nodes[i];
+        AccelNodeQ q;
+        for (int s = 0; s < 2; ++s) {
+            for (int a = 0; a < 3; ++a) {
+                const double lo = floor(((double)nd.lo[s][a] - g.gmin[a]) / g.cell[a]) - 1.0;
+                const double hi = ceil(((double)nd.hi[s][a] - g.gmin[a]) / g.cell[a]) + 1.0;
+                // (an empty child box, lo = +max and hi = -max, becomes [65535, 0]: still empty)
+                q.lo[a][s] = (uint16_t)fmin(fmax(lo, 0.0), 65535.0);
+                q.hi[a][s] = (uint16_t)fmin(fmax(hi, 0.0), 65535.0);
+            }
+            q.child[s] = nd.child[s];
+        }
+        out[i] = q;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Tree build on the device (pt_scene_build_device): Morton codes of the primitives' centres, a radix sort, a gather
 // of the 64-B primitive records into curve order; the boxes then come from the refit kernels above.

@@ -165,6 +165,9 @@ struct pt_ctx {
     bool use_accel = true;         // fast mode: SAH tree for scenes that are not a short list (PTGPU_ACCEL=0 disables)
     bool accel_ok = false;
     void *d_accel_nodes = nullptr, *d_accel_prims = nullptr, *d_accel_parent = nullptr, *d_accel_levels = nullptr;
+    void *d_accel_nodes_q = nullptr; // the nodes in their 32-byte form (trees of kAccelQuantFrom nodes and more), else null
+    AccelGrid accel_grid_q{};
+    int32_t n_accel_nodes = 0;
     std::vector<std::pair<int32_t, int32_t>> accel_levels; // refit order (deepest level first): index ranges of d_accel_levels, or node id ranges when that is null
     int accel_depth = 0;
     int32_t n_accel_prims = 0;
@@ -335,8 +338,14 @@ template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
     if (!X && ctx->accel_ok && a.counters == nullptr && ctx->accel_pool && !(ctx->accel_pool_from > a.depth && a.key_mode == 0)) {
         grid = std::min(grid, ctx->n_cu * (MEDIA ? 4 : 5) * (int)ctx->accel_grid); // what is resident at once
-        hipLaunchKernelGGL((k_extend_accel_pool<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
-                           (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a, ctx->accel_refill | (ctx->accel_inner << 8));
+        if (ctx->d_accel_nodes_q)
+            hipLaunchKernelGGL((k_extend_accel_pool<MEDIA, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
+                               (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a,
+                               ctx->accel_refill | (ctx->accel_inner << 8), (const AccelNodeQ *)ctx->d_accel_nodes_q, ctx->accel_grid_q);
+        else
+            hipLaunchKernelGGL((k_extend_accel_pool<MEDIA, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
+                               (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a,
+                               ctx->accel_refill | (ctx->accel_inner << 8), (const AccelNodeQ *)nullptr, AccelGrid{});
     } else if (!X && ctx->accel_ok && a.counters == nullptr) {
         hipLaunchKernelGGL((k_extend_accel<MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
                            (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a);
@@ -522,6 +531,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                (const DevOp *)ctx->d_accel_prims, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
                                ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
         };
+        // (the 32-byte nodes the extend kernel reads on big trees cost this kernel 12 more registers of ray state: at
+        // 128 VGPRs that is 80 B more scratch per lane, and the million-sphere render ran 588 -> 503 Mpaths/s)
         with_tex(ctx->tex, [&](auto T) {
             constexpr int kTex = decltype(T)::value;
             if (media) launch(k_tree_pool<kTex, true>);
@@ -713,6 +724,7 @@ void apply_tuning_overrides(pt_tuning &t) {
 // extern "C"
 // ================================================================================================================
 extern "C" {
+static int quantise_nodes(pt_ctx *ctx);
 
 int pt_create(const pt_config *cfg, pt_ctx **out) {
     // the structure of ABI version 1 ended before `tuning`: still accepted, with the defaults
@@ -763,7 +775,7 @@ void pt_destroy(pt_ctx *ctx) {
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
-                    ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts,
+                    ctx->d_accel_nodes_q, ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts,
                     ctx->d_stage[0], ctx->d_stage[1]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -938,6 +950,8 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
                 ctx->accel_levels.emplace_back(acc.level_start[l], acc.level_start[l + 1]);
             ctx->accel_depth = acc.depth;
             ctx->n_accel_prims = (int32_t)acc.prims.size();
+            ctx->n_accel_nodes = (int32_t)acc.nodes.size();
+            if ((rc = quantise_nodes(ctx)) != PT_OK) return rc;
             ctx->accel_ok = true;
             // Camera rays through a small tree take similar numbers of steps, and a ray per thread is then the
             // faster form (measured on ~500 spheres: +9 % on the render); bigger trees gain from the lane pool at
@@ -1226,6 +1240,35 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     return PT_OK;
 }
 
+// (Re)makes the 32-byte form of the nodes from the f32 nodes on the device; big trees only. The grid spans the root's
+// two child boxes, i.e. the scene as the tree sees it now.
+static int quantise_nodes(pt_ctx *ctx) {
+    if (ctx->d_accel_nodes_q) {
+        (void)hipFree(ctx->d_accel_nodes_q);
+        ctx->d_accel_nodes_q = nullptr;
+    }
+    const int32_t n = ctx->n_accel_nodes;
+    if (n < kAccelQuantFrom) return PT_OK;
+    AccelNode root;
+    HIP_TRY(ctx, hipMemcpyAsync(&root, ctx->d_accel_nodes, sizeof(root), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AccelGrid g;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = std::min((double)root.lo[0][a], (double)root.lo[1][a]);
+        const double hi = std::max((double)root.hi[0][a], (double)root.hi[1][a]);
+        if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return PT_OK; // nothing to quantise against
+        g.gmin[a] = lo;
+        g.cell[a] = hi > lo ? (hi - lo) / 65535.0 * (1.0 + 1e-12) : 1.0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_accel_nodes_q, (size_t)n * sizeof(AccelNodeQ)));
+    hipLaunchKernelGGL(k_accel_quantise, dim3(grid_for(ctx, (uint32_t)n)), dim3(kBlock), 0, ctx->stream,
+                       (const AccelNode *)ctx->d_accel_nodes, (AccelNodeQ *)ctx->d_accel_nodes_q, n, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->accel_grid_q = g;
+    return PT_OK;
+}
+
 // Bounds of every primitive for [time0, time1], pushed up the tree one launch per level, deepest level first.
 static int refit_levels(pt_ctx *ctx, double time0, double time1) {
     for (const auto &lv : ctx->accel_levels) {
@@ -1238,7 +1281,7 @@ static int refit_levels(pt_ctx *ctx, double time0, double time1) {
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return quantise_nodes(ctx);
 }
 
 int pt_scene_refit(pt_ctx *ctx, double time0, double time1) {
@@ -1337,6 +1380,7 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
     ctx->d_accel_levels = nullptr; // node ids are level-ordered already
     ctx->accel_levels.assign(levels.rbegin(), levels.rend());
     ctx->accel_depth = (int)levels.size();
+    ctx->n_accel_nodes = end; // nodes the build created
     ctx->accel_ok = false; // until the boxes are in
     if ((rc = refit_levels(ctx, time0, time1)) != PT_OK) return rc;
     ctx->accel_ok = true;

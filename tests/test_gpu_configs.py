@@ -201,6 +201,44 @@ def test_tree_traversal_forms_agree(name, param):
     assert (base[0]["prim"] >= 0).mean() > 0.1
 
 
+def test_big_tree_in_32_byte_nodes():
+    """Trees of 32 768 nodes and more are also kept with their boxes quantised to 16 bits on the scene's grid (half
+    the loads per node visit), and the refilled-lane extend kernel walks that form. The quantised boxes contain the
+    f32 ones, so the hits are those of the f32 tree, bit for bit: camera rays, incoherent secondary rays, rays that run
+    parallel to one, two or all three axes (an infinite or undefined reciprocal direction), and the same again after
+    a refit and after a rebuild of the tree on the device (both remake the quantised nodes)."""
+    scene = ptgpu.Scene.named("sphere_cloud", 1.0, param=150000)
+    assert scene.accel_info()["n_nodes"] >= 32768
+    primary, secondary = _rays(scene, 160, 160)
+    special = np.zeros(12, dtype=ptgpu.RAY_DTYPE)
+    special["origin"] = [(500.3, 500.1, -10.0)] * 4 + [(-10.0, 499.7, 500.2)] * 4 + [(500.0, 500.0, 500.0)] * 4
+    special["direction"] = [(0, 0, 1), (0, 0, 2.5), (1e-300, 0, 1), (0, 1e-9, 1), (1, 0, 0), (3, 0, 0), (1, 0, 1e-12), (1, 1, 0),
+                            (0, 0, 0), (0, -1, 0), (-1, 0, 0), (0, 0, -1)]
+    batches = [primary, secondary, special]
+
+    def run(steps, **tuning):
+        ctx = _ctx(max_paths_in_flight=1 << 16, **tuning)
+        ctx.upload(scene)
+        out = []
+        for step in steps:
+            if step == "refit":
+                ctx.refit(0.0, 1.0)
+            elif step == "build":
+                ctx.build_tree_on_device(0.0, 1.0)
+            out.append([ctx.intersect(b) for b in batches])
+        ctx.close()
+        return out
+
+    f32_nodes = run(["upload", "refit", "build"], accel_form=1)   # a ray per thread reads the f32 nodes
+    quantised = run(["upload", "refit", "build"])                 # the lane pool reads the 32-byte nodes
+    for stage, (a_all, b_all) in enumerate(zip(f32_nodes, quantised)):
+        for a, b in zip(a_all, b_all):
+            assert np.array_equal(a["prim"], b["prim"]), stage
+            assert np.array_equal(a["t"], b["t"], equal_nan=True), stage
+    assert (f32_nodes[0][0]["prim"] >= 0).mean() > 0.1
+    assert (f32_nodes[0][2]["prim"] >= 0).any()
+
+
 @pytest.mark.parametrize("name,param,rflags", [("random_scene", 0, 0), ("final_book_two", 0, 0),
                                                ("final_book_two", 1, ptgpu.PT_RENDER_BOOK_SEMANTICS), ("sphere_cloud", 50000, 0)])
 def test_tree_pool_gives_the_same_image(name, param, rflags):
