@@ -214,12 +214,17 @@ template <> struct TreePoolTexLds<2> {
     double ps[kWavesPerBlock][64][3];
     double rs[kWavesPerBlock][9][8];
 };
-template <int TEX, bool MEDIA>
+// RT: a realtime frame (src/trace.rs:144-146: four of five pixels are skipped, by a draw keyed on seed, frame and
+// pixel). The path ids of a frame cover every pixel; a wave evaluates the skip draw of 64 ids at a time with all its
+// lanes, parks the ids that survive in LDS, and free lanes take their paths from there.
+template <int TEX, bool MEDIA, bool RT = false>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk) {
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
+    __shared__ uint32_t live[RT ? kWavesPerBlock : 1][64]; // RT: surviving path ids of the wave, not yet taken
+    uint32_t live_n = 0;
     const uint32_t refill_at = min(max(tuning & 0xffu, 1u), 64u), inner_min = (tuning >> 8) & 0xffu, shade_min = (tuning >> 16) & 0xffu,
                    trav_min = tuning >> 24;
     constexpr int32_t kDone = INT32_MIN; // never a leaf reference
@@ -257,47 +262,94 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
         const double probe = (o.x + o.y + o.z) + (d.x + d.y + d.z);
         node = (probe == probe && fabs(probe) <= kF64Max) ? 0 : kDone;
     };
+    // pixel of the h-th path id of the pass
+    auto pixel_of = [&](const PassParams &pp, uint32_t h, uint32_t &i, uint32_t &jy, uint32_t &smp) -> uint64_t {
+        const uint32_t p = h % pp.cpix;
+        smp = h / pp.cpix;
+        i = pp.cx0 + p % pp.cw;
+        jy = pp.cy0 + (p / pp.cw) * pp.row_step;
+        return (uint64_t)jy * pp.width + i;
+    };
+    // the calling lanes start path id h: camera sample (src/trace.rs:153-156, Camera::get_ray src/camera.rs:53-59)
+    auto take_path = [&](uint32_t h) {
+        const PoolConsts *pc = consts;
+        asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+        const CameraDev cam = pc->cam;
+        const PassParams pp = pc->pp;
+        pid = h;
+        uint32_t i, jy, smp;
+        const uint64_t pixel = pixel_of(pp, h, i, jy, smp);
+        Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + smp), 0};
+        double random = g.next();
+        const double u = ((double)i + random) / (double)pp.width;
+        random = g.next();
+        const double v = ((double)jy + random) / (double)pp.height;
+        const D3 rd = random_in_unit_disk(g) * cam.lens_radius;
+        const D3 offset = cam.u * rd.x + cam.v * rd.y;
+        time = cam.time0 + g.next() * (cam.time1 - cam.time0);
+        d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
+        o = cam.origin + offset;
+        beta = d3(1.0, 1.0, 1.0);
+        pkey = g.key;
+        rn = g.n;
+        depth = 0;
+        has = true;
+        start_ray();
+    };
+    // the wave's next chunk of path ids, when the current one is used up
+    auto next_chunk = [&]() {
+        if (cur >= end && !exhausted) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            exhausted = first >= n;
+            cur = min(first, n);
+            end = min(cur + chunk, n);
+        }
+    };
     for (;;) {
-        const unsigned long long idle = __ballot(!has);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle >= refill_at) {
-            if (cur >= end && !exhausted) {
-                uint32_t first = 0;
-                if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
-                first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-                exhausted = first >= n;
-                cur = min(first, n);
-                end = min(cur + chunk, n);
+        unsigned long long idle = __ballot(!has);
+        uint32_t n_idle = (uint32_t)__popcll(idle);
+        if constexpr (RT) {
+            bool drained = false;
+            while (n_idle >= refill_at) {
+                if (live_n == 0) { // the skip draws of the next 64 ids, by all lanes
+                    next_chunk();
+                    if (cur >= end) {
+                        drained = n_idle == 64;
+                        break;
+                    }
+                    const PoolConsts *pc = consts;
+                    asm volatile("" : "+s"(pc));
+                    const PassParams pp = pc->pp;
+                    const uint32_t h = cur + lane;
+                    bool alive = false;
+                    if (h < end) {
+                        uint32_t i, jy, smp;
+                        const uint64_t pixel = pixel_of(pp, h, i, jy, smp);
+                        alive = !(pixel_skip_draw(pp.seed, pp.frame, pixel) < 0.8); // src/trace.rs:144
+                    }
+                    const unsigned long long mask = __ballot(alive);
+                    if (alive) live[threadIdx.x >> 6][__popcll(mask & ((1ull << lane) - 1ull))] = h;
+                    live_n = (uint32_t)__popcll(mask);
+                    cur = min(cur + 64u, end);
+                    wave_lds_fence();
+                    if (live_n == 0) continue;
+                }
+                const uint32_t take = min(n_idle, live_n);
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!has && rank < take) take_path(live[threadIdx.x >> 6][live_n - 1u - rank]);
+                live_n -= take;
+                wave_lds_fence(); // the slots just read may be written again
+                idle = __ballot(!has);
+                n_idle = (uint32_t)__popcll(idle);
             }
+            if (drained) break; // nothing in flight, nothing left to start
+        } else if (n_idle >= refill_at) {
+            next_chunk();
             if (cur < end) {
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (!has && cur + rank < end) {
-                    const PoolConsts *pc = consts;
-                    asm volatile("" : "+s"(pc)); // keeps the loads below in this block
-                    const CameraDev cam = pc->cam;
-                    const PassParams pp = pc->pp;
-                    pid = cur + rank;
-                    const uint32_t p = pid % pp.cpix, s = pid / pp.cpix;
-                    const uint32_t i = pp.cx0 + p % pp.cw;
-                    const uint32_t jy = pp.cy0 + (p / pp.cw) * pp.row_step;
-                    const uint64_t pixel = (uint64_t)jy * pp.width + i;
-                    Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + s), 0};
-                    double random = g.next(); // src/trace.rs:153-156
-                    const double u = ((double)i + random) / (double)pp.width;
-                    random = g.next();
-                    const double v = ((double)jy + random) / (double)pp.height;
-                    const D3 rd = random_in_unit_disk(g) * cam.lens_radius; // Camera::get_ray, src/camera.rs:53-59
-                    const D3 offset = cam.u * rd.x + cam.v * rd.y;
-                    time = cam.time0 + g.next() * (cam.time1 - cam.time0);
-                    d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
-                    o = cam.origin + offset;
-                    beta = d3(1.0, 1.0, 1.0);
-                    pkey = g.key;
-                    rn = g.n;
-                    depth = 0;
-                    has = true;
-                    start_ray();
-                }
+                if (!has && cur + rank < end) take_path(cur + rank);
                 cur = min(cur + n_idle, end);
             } else if (n_idle == 64) {
                 break; // nothing in flight, nothing left to start

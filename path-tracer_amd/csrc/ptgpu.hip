@@ -439,7 +439,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
                        ctx->view.n_leaves <= kLdsLeaves;
-    const bool tree = !fused && !realtime && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count;
+    const bool tree = !fused && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count; // offline passes and realtime frames
     const bool persistent = fused && !pool;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
@@ -535,8 +535,11 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         // 128 VGPRs that is 80 B more scratch per lane, and the million-sphere render ran 588 -> 503 Mpaths/s)
         with_tex(ctx->tex, [&](auto T) {
             constexpr int kTex = decltype(T)::value;
-            if (media) launch(k_tree_pool<kTex, true>);
-            else launch(k_tree_pool<kTex, false>);
+            if (realtime) {
+                if (media) launch(k_tree_pool<kTex, true, true>);
+                else launch(k_tree_pool<kTex, false, true>);
+            } else if (media) launch(k_tree_pool<kTex, true, false>);
+            else launch(k_tree_pool<kTex, false, false>);
         });
         HIP_TRY(ctx, mark());
     }

@@ -137,6 +137,48 @@ def test_realtime_1080p_frames():
     ctx.close()
 
 
+def test_realtime_frames_of_a_tree_scene():
+    """Realtime frames (80 % pixel skip, running blend, src/trace.rs:144-177) of a scene that is traced through the SAH
+    tree: one pool launch per frame, whose waves evaluate the skip draw of 64 path ids at a time and hand the survivors
+    to their free lanes, against ray generation plus an extend and a shade launch per bounce. Bit-identical images and
+    segment counts over several frames, at widths that leave ragged chunks; and the frames agree with the oracle's."""
+    scene = ptgpu.Scene.named("random_scene", 3 / 2)
+
+    def run(w, h, frames, **tuning):
+        ctx = _ctx(max_paths_in_flight=1 << 16, **tuning)
+        ctx.upload(scene)
+        ctx.reset()
+        forms = set()
+        for frame in range(frames):
+            ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=frame)
+            forms.add(int(ctx.stats().last_pass_form))
+        img, st = ctx.readback(), ctx.stats()
+        ctx.close()
+        return img, st, forms
+
+    for w, h in ((150, 100), (67, 31)):
+        a, st_a, forms_a = run(w, h, 5, pass_form=ptgpu.PT_PASS_PER_BOUNCE)
+        assert forms_a == {ptgpu.PT_PASS_PER_BOUNCE}
+        for tuning in ({}, {"tree_refill": 1, "pool_chunk": 64}, {"tree_refill": 64, "tree_shade": 64, "pool_chunk": 4096}):
+            b, st_b, forms_b = run(w, h, 5, **tuning)
+            assert forms_b == {ptgpu.PT_PASS_TREE_POOL}, tuning
+            assert st_b.launches_extend == 0 and st_b.launches_raygen == 0
+            assert np.array_equal(a, b, equal_nan=True), (w, h, tuning)
+            assert int(st_a.segments) == int(st_b.segments), tuning
+    # against the oracle's frames
+    w, h = 96, 64
+    got, _, _ = run(w, h, 4)
+    ref = np.zeros((h, w, 4), dtype=np.float32)
+    counts = np.zeros((h, w), dtype=np.uint32)
+    for frame in range(4):
+        ob.render(scene.desc(), scene.camera, w, h, 1, 10, seed=0x5EED0001, mode=1, frame=frame, threads=8, image=ref, counts=counts)
+    touched = counts > 0
+    assert 0.4 < touched.mean() < 0.8            # 1 - 0.8^4 = 0.59
+    assert (got[~touched][..., :3] == 0).all()
+    close = np.isclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6)
+    assert close.mean() >= 0.995
+
+
 def test_pass_forms_give_the_same_image():
     """The ways a list scene's offline pass can be run -- one launch whose waves keep a pool of paths in registers and
     generate their own camera samples (the default), ray generation plus one launch of persistent waves over queue
