@@ -51,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--realtime", action="store_true",
                     help="progressive frames instead of the offline render (src/lib.rs:118-123: spp 1, depth 10, "
                          "80 %% pixel skip, running mean); pass --width 1920 --height 1080 --steps <frames>")
+    ap.add_argument("--present", choices=["none", "readback", "ring"], default="none",
+                    help="--realtime on one GPU: every frame also goes to host memory, as the reference hands its buffer to "
+                         "the presentation graph (src/lib.rs:496-509): 'readback' = pt_readback after each frame, 'ring' = "
+                         "pt_present_submit into a two-slot ring, waiting for a frame only when the next one has been traced")
     ap.add_argument("--gather", choices=["capi", "torch"], default="capi",
                     help="N > 1: rows to rank 0 through pt_group_gather (RCCL inside the library) or torch.distributed.gather")
     args = ap.parse_args(argv)
@@ -214,10 +218,19 @@ def main():
             else:
                 tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
 
+        ring = None
+        if args.present == "ring" and world == 1:
+            ring = ctx.present_attach(None, slots=2, width=W, height=H)  # the library's page-locked ring
+
         def step(frame):
             ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, flags=rflags, rows=rows)
             if world > 1:
                 gather()
+            elif args.present == "readback":
+                ctx.readback()
+            elif ring is not None:
+                ctx.present_submit(frame & 1)
+                ctx.present_wait((frame & 1) ^ 1)  # the frame before this one is shown now
 
         def barrier():
             if dist is not None:
@@ -315,6 +328,7 @@ def main():
                 "world_size": world,
                 "paths_in_flight": args.paths_in_flight,
                 "frames_per_s": (args.steps / elapsed) if args.realtime else None,
+                "present": args.present,
                 "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
                 "nan_pixel_fraction": nan_frac,
                 "book_semantics": bool(args.book_semantics),

@@ -441,6 +441,32 @@ int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes);
  * of the screen (the shader's uv.y flip), alpha 1. */
 int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_floats);
 
+/* ---- presentation bridge ----
+ * Replaces the per-frame hand-over of the traced image to the presentation graph: the main loop owns the f32 RGBA
+ * buffer the tile jobs write (src/lib.rs:496-509) and the CopyToImage node records a copy of the host-visible source
+ * buffer into the sampled image that the tonemap pass then draws (src/node/copy_image.rs:104-165,
+ * src/lib.rs:241-292).
+ * Here the image lives on the GPU that traced it, and frames reach host memory through a RING of n_slots frames of
+ * slot_bytes each (at most 4), attached once. host_staging NULL: the library allocates the ring as page-locked host
+ * memory, which the GPU's copy engines write at the full rate of the link; pt_present_slot returns a slot's address,
+ * and the host uploads from there (or imports the allocation as external host memory). host_staging non-NULL: the
+ * host's own memory (the mapped source buffer of that node); its pages are pinned where the driver allows it, and
+ * memory it refuses to pin is accepted too and copied through the runtime's bounce buffers at a fraction of the
+ * link's rate (pt_present_pinned tells which). pt_present_submit snapshots the context's current image for a slot on
+ * the render stream (PT_PRESENT_RAW: the f32 RGBA image as traced, row 0 = bottom scanline, what the node uploads;
+ * PT_PRESENT_DISPLAY: pt_display_transform's output at `exposure`, row 0 = top of the screen, for a host that only
+ * blits), queues the snapshot's copy into the slot on a second stream and returns: the next frame is traced while
+ * the previous one crosses PCIe. pt_present_wait blocks until a slot's bytes are in host memory (a slot never
+ * submitted is ready at once); submitting to a slot waits for that slot's previous copy first. The first submit of a
+ * slot (and the first after the image grew) allocates its device snapshot. pt_destroy detaches. */
+enum pt_present_kind { PT_PRESENT_RAW = 0, PT_PRESENT_DISPLAY = 1 };
+int pt_present_attach(pt_ctx *ctx, void *host_staging, size_t slot_bytes, uint32_t n_slots);
+void *pt_present_slot(pt_ctx *ctx, uint32_t slot);   /* host address of a slot; NULL if there is none */
+int pt_present_pinned(pt_ctx *ctx);                  /* 1 if the attached ring is page-locked, else 0 */
+int pt_present_submit(pt_ctx *ctx, uint32_t slot, int kind, float exposure);
+int pt_present_wait(pt_ctx *ctx, uint32_t slot);
+int pt_present_detach(pt_ctx *ctx);
+
 /* ---- realtime interaction (host side) ----
  * Key bits of pt_user_input: the keys the reference's main loop and camera react to
  * (src/camera.rs:121-189, src/lib.rs:425-451). */

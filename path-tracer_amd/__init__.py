@@ -243,7 +243,7 @@ EXPORTS = [
     "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_scene_build_device",
     "pt_abi_version", "pt_intersect_static", "pt_asset_register_image", "pt_group_unique_id", "pt_group_join",
     "pt_group_join_local", "pt_group_rows", "pt_group_gather", "pt_group_gather_local", "pt_group_leave",
-    "pt_group_loopback",
+    "pt_group_loopback", "pt_present_attach", "pt_present_slot", "pt_present_pinned", "pt_present_submit", "pt_present_wait", "pt_present_detach",
 ]
 
 _vp = C.c_void_p
@@ -318,6 +318,13 @@ _sig("pt_group_gather", C.c_int, _vp, C.c_int)
 _sig("pt_group_gather_local", C.c_int, C.POINTER(_vp), C.c_int, C.c_int)
 _sig("pt_group_leave", C.c_int, _vp)
 _sig("pt_group_loopback", C.c_int, _vp)
+_sig("pt_present_attach", C.c_int, _vp, _vp, C.c_size_t, C.c_uint32)
+_sig("pt_present_slot", _vp, _vp, C.c_uint32)
+_sig("pt_present_pinned", C.c_int, _vp)
+_sig("pt_present_submit", C.c_int, _vp, C.c_uint32, C.c_int, C.c_float)
+_sig("pt_present_wait", C.c_int, _vp, C.c_uint32)
+_sig("pt_present_detach", C.c_int, _vp)
+PT_PRESENT_RAW, PT_PRESENT_DISPLAY = 0, 1
 _sig("pt_abi_version", C.c_uint32)
 _sig("pt_intersect_static", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
 PT_INTERSECT_STATIC_MAX_RAYS = 65536
@@ -611,6 +618,36 @@ class Context:
         self._check(lib.pt_display_transform(self._h, float(exposure), out.ctypes.data_as(C.POINTER(C.c_float)), out.size),
                     "pt_display_transform")
         return out
+
+    def present_attach(self, staging=None, slots=2, width=None, height=None):
+        """Attaches the presentation ring (pt_present_attach) and returns it as a float32 array of shape
+        (slots, height, width, 4). `staging`: a C-contiguous array of that shape owned by the caller (it must outlive
+        the attachment); None: the library allocates page-locked memory for `slots` frames of width x height."""
+        if staging is not None:
+            assert staging.dtype == np.float32 and staging.flags["C_CONTIGUOUS"] and staging.ndim == 4
+            self._check(lib.pt_present_attach(self._h, staging.ctypes.data, staging[0].nbytes, staging.shape[0]), "pt_present_attach")
+            self._present_staging = staging
+            return staging
+        width, height = width or self.width, height or self.height
+        slot_bytes = width * height * 16
+        self._check(lib.pt_present_attach(self._h, None, slot_bytes, slots), "pt_present_attach")
+        base = lib.pt_present_slot(self._h, 0)
+        ring = np.ctypeslib.as_array((C.c_float * (slots * height * width * 4)).from_address(base)).reshape(slots, height, width, 4)
+        self._present_staging = ring  # a view of the library's memory: invalid after present_detach / close
+        return ring
+
+    def present_pinned(self):
+        return bool(lib.pt_present_pinned(self._h))
+
+    def present_submit(self, slot, kind=PT_PRESENT_RAW, exposure=1.3):
+        self._check(lib.pt_present_submit(self._h, slot, kind, float(exposure)), "pt_present_submit")
+
+    def present_wait(self, slot):
+        self._check(lib.pt_present_wait(self._h, slot), "pt_present_wait")
+
+    def present_detach(self):
+        self._check(lib.pt_present_detach(self._h), "pt_present_detach")
+        self._present_staging = None
 
     def stats(self) -> Stats:
         s = Stats()

@@ -331,7 +331,48 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
     }
     int32_t child, count;
     Box box;
-    bld.build_child(0, (int)bld.prims.size(), 0, child, count, box);
+    // Primitives that span the scene (a fog medium around everything, the ground sphere of random_scene) would drag a
+    // scene-sized box down every level the SAH needs to separate them from the primitives whose centres lie near
+    // theirs: a spine of nodes every ray has to visit. They become the root's first child instead, one leaf, and the
+    // tree over the other primitives its second. A ray is inside both boxes from the start, the traversal takes the
+    // first child on a tie, so the lanes that start rays together also test these primitives together, and every
+    // later box test has their hit distance to cull with.
+    int n_wide = 0;
+    {
+        Box all;
+        all.clear();
+        for (const BuildPrim &q : bld.prims) all.grow(q.box);
+        const double wide = 0.5 * all.half_area();
+        auto mid = std::stable_partition(bld.prims.begin(), bld.prims.end(),
+                                         [&](const BuildPrim &q) { return q.box.half_area() >= wide; });
+        n_wide = (int)(mid - bld.prims.begin());
+    }
+    const int n_all = (int)bld.prims.size();
+    if (n_wide >= 1 && n_wide <= Builder::kLeafMax && n_all - n_wide >= 2) {
+        bld.nodes.emplace_back();
+        std::memset(&bld.nodes[0], 0, sizeof(AccelNode));
+        Box b[2];
+        int32_t c[2];
+        b[0].clear();
+        c[0] = accel_leaf_ref(0, n_wide);
+        for (int i = 0; i < n_wide; ++i) {
+            b[0].grow(bld.prims[i].box);
+            bld.order.push_back(bld.prims[i].op);
+        }
+        bld.build_child(n_wide, n_all - n_wide, 1, c[1], count, b[1]);
+        AccelNode &root = bld.nodes[0];
+        for (int s = 0; s < 2; ++s) {
+            for (int a = 0; a < 3; ++a) {
+                root.lo[s][a] = round_down(b[s].lo[a]);
+                root.hi[s][a] = round_up(b[s].hi[a]);
+            }
+            root.child[s] = c[s];
+        }
+        bld.max_depth = std::max(bld.max_depth, 1);
+        child = 0;
+    } else {
+        bld.build_child(0, n_all, 0, child, count, box);
+    }
     if (bld.too_deep || child != 0) { // child != 0: the whole scene became one leaf
         error = "tree too deep or degenerate";
         return false;

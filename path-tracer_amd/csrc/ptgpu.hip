@@ -186,6 +186,20 @@ struct pt_ctx {
     // membership in a group of contexts, one per GPU, that render one image together (pt_group_*)
     ncclComm_t comm = nullptr;
     int group_rank = 0, group_world = 1;
+
+    // presentation ring (pt_present_*): the host's staging memory, pinned, and one device snapshot per slot
+    static constexpr uint32_t kPresentSlots = 4;
+    unsigned char *present_host = nullptr;
+    void *present_pinned = nullptr;                  // start of the pinned page range, null if pinning was refused
+    bool present_owned = false;                      // the ring is the library's own hipHostMalloc allocation
+    size_t present_slot_bytes = 0;
+    uint32_t present_slots = 0;
+    hipStream_t present_stream = nullptr;            // carries the copies to the host, beside the render stream
+    void *d_present[kPresentSlots] = {};             // snapshot of the frame a slot shows
+    size_t present_bytes[kPresentSlots] = {};
+    hipEvent_t ev_snapshot[kPresentSlots] = {};      // render stream: the slot's snapshot is complete
+    hipEvent_t ev_landed[kPresentSlots] = {};        // copy stream: the slot's bytes are in host memory
+    bool present_pending[kPresentSlots] = {};
 };
 
 namespace {
@@ -775,6 +789,7 @@ void pt_destroy(pt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && rccl_api()) (void)rccl_api()->CommDestroy(ctx->comm);
+    (void)pt_present_detach(ctx);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
@@ -1243,6 +1258,128 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     return PT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Presentation ring: frames leave the GPU while the next ones are traced. A slot's frame is first snapshotted on the
+// render stream (a device copy, or the display transform written straight into the snapshot), so the image may be
+// traced into again at once; the snapshot then crosses PCIe on a second stream into the host's pinned staging memory.
+// ---------------------------------------------------------------------------------------------------------------
+int pt_present_attach(pt_ctx *ctx, void *host_staging, size_t slot_bytes, uint32_t n_slots) {
+    if (!ctx || slot_bytes == 0 || n_slots == 0 || n_slots > pt_ctx::kPresentSlots) return PT_ERR_INVALID_ARG;
+    if (ctx->present_host) return set_error(ctx, PT_ERR_INVALID_ARG, "a staging buffer is attached already: pt_present_detach first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!host_staging) {
+        // the library's own ring: page-locked host memory the copy engines write at the full rate of the link
+        void *ring = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&ring, slot_bytes * n_slots, hipHostMallocDefault));
+        host_staging = ring;
+        ctx->present_owned = true;
+    } else {
+        // The caller's memory: whole pages are pinned where the driver allows it. Memory it refuses to pin (some
+        // mapped device allocations; every user pointer for a process without the privilege) is still accepted:
+        // its copies then pass through the runtime's own bounce buffers, at a fraction of the link's rate.
+        const uintptr_t page = 4096, lo = (uintptr_t)host_staging & ~(page - 1);
+        const uintptr_t hi = ((uintptr_t)host_staging + slot_bytes * n_slots + page - 1) & ~(page - 1);
+        ctx->present_pinned = hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess ? (void *)lo : nullptr;
+        (void)hipGetLastError();
+    }
+    auto fail = [&](hipError_t e, const char *what) {
+        ctx->present_host = (unsigned char *)host_staging; // so that detach releases what was made
+        (void)pt_present_detach(ctx);
+        return set_error(ctx, PT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    if (hipError_t e = hipStreamCreateWithFlags(&ctx->present_stream, hipStreamNonBlocking); e != hipSuccess)
+        return fail(e, "hipStreamCreateWithFlags");
+    for (uint32_t k = 0; k < n_slots; ++k) {
+        if (hipError_t e = hipEventCreateWithFlags(&ctx->ev_snapshot[k], hipEventDisableTiming); e != hipSuccess)
+            return fail(e, "hipEventCreateWithFlags");
+        if (hipError_t e = hipEventCreateWithFlags(&ctx->ev_landed[k], hipEventDisableTiming); e != hipSuccess)
+            return fail(e, "hipEventCreateWithFlags");
+    }
+    ctx->present_host = (unsigned char *)host_staging;
+    ctx->present_slot_bytes = slot_bytes;
+    ctx->present_slots = n_slots;
+    return PT_OK;
+}
+
+void *pt_present_slot(pt_ctx *ctx, uint32_t slot) {
+    if (!ctx || !ctx->present_host || slot >= ctx->present_slots) return nullptr;
+    return ctx->present_host + (size_t)slot * ctx->present_slot_bytes;
+}
+
+int pt_present_pinned(pt_ctx *ctx) { return ctx && ctx->present_host && (ctx->present_owned || ctx->present_pinned) ? 1 : 0; }
+
+int pt_present_wait(pt_ctx *ctx, uint32_t slot) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->present_host || slot >= ctx->present_slots) return set_error(ctx, PT_ERR_INVALID_ARG, "no such presentation slot");
+    if (ctx->present_pending[slot]) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_landed[slot]));
+        ctx->present_pending[slot] = false;
+    }
+    return PT_OK;
+}
+
+int pt_present_submit(pt_ctx *ctx, uint32_t slot, int kind, float exposure) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->present_host || slot >= ctx->present_slots) return set_error(ctx, PT_ERR_INVALID_ARG, "no such presentation slot");
+    if (kind != PT_PRESENT_RAW && kind != PT_PRESENT_DISPLAY) return set_error(ctx, PT_ERR_INVALID_ARG, "unknown pt_present_kind");
+    if (!ctx->d_image || ctx->width == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "no image: render first");
+    const size_t need = (size_t)ctx->width * ctx->height * 4 * sizeof(float);
+    if (need > ctx->present_slot_bytes) return set_error(ctx, PT_ERR_TOO_LARGE, "the image does not fit a presentation slot");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the slot's previous frame must have left its snapshot before the snapshot is overwritten
+    if (int rc = pt_present_wait(ctx, slot); rc != PT_OK) return rc;
+    if (ctx->present_bytes[slot] < need) {
+        if (ctx->d_present[slot]) (void)hipFree(ctx->d_present[slot]);
+        ctx->d_present[slot] = nullptr;
+        ctx->present_bytes[slot] = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_present[slot], need));
+        ctx->present_bytes[slot] = need;
+    }
+    if (kind == PT_PRESENT_RAW) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_present[slot], ctx->d_image, need, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        const uint32_t n = ctx->width * ctx->height;
+        hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image,
+                           ctx->width, ctx->height, exposure, (float *)ctx->d_present[slot]);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_snapshot[slot], ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->present_stream, ctx->ev_snapshot[slot], 0));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->present_host + (size_t)slot * ctx->present_slot_bytes, ctx->d_present[slot], need,
+                                hipMemcpyDeviceToHost, ctx->present_stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_landed[slot], ctx->present_stream));
+    ctx->present_pending[slot] = true;
+    return PT_OK;
+}
+
+int pt_present_detach(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->present_host) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->present_stream) {
+        (void)hipStreamSynchronize(ctx->present_stream);
+        (void)hipStreamDestroy(ctx->present_stream);
+        ctx->present_stream = nullptr;
+    }
+    if (ctx->present_pinned) (void)hipHostUnregister(ctx->present_pinned);
+    if (ctx->present_owned) (void)hipHostFree(ctx->present_host);
+    ctx->present_pinned = nullptr;
+    ctx->present_owned = false;
+    for (uint32_t k = 0; k < pt_ctx::kPresentSlots; ++k) {
+        if (ctx->ev_snapshot[k]) (void)hipEventDestroy(ctx->ev_snapshot[k]);
+        if (ctx->ev_landed[k]) (void)hipEventDestroy(ctx->ev_landed[k]);
+        if (ctx->d_present[k]) (void)hipFree(ctx->d_present[k]);
+        ctx->ev_snapshot[k] = ctx->ev_landed[k] = nullptr;
+        ctx->d_present[k] = nullptr;
+        ctx->present_bytes[k] = 0;
+        ctx->present_pending[k] = false;
+    }
+    ctx->present_host = nullptr;
+    ctx->present_slot_bytes = 0;
+    ctx->present_slots = 0;
+    return PT_OK;
+}
+
 // (Re)makes the 32-byte form of the nodes from the f32 nodes on the device; big trees only. The grid spans the root's
 // two child boxes, i.e. the scene as the tree sees it now.
 static int quantise_nodes(pt_ctx *ctx) {
@@ -1431,6 +1568,17 @@ int pt_stats_reset(pt_ctx *ctx) {
         if (r_ != ncclSuccess) return set_error(ctx, PT_ERR_COMM, std::string(#expr) + ": " + nccl->GetErrorString(r_)); \
     } while (0)
 
+// Inside a GroupStart / GroupEnd pair: a failed call still closes the group before the error is returned, so that the
+// communicator is not left collecting operations.
+#define NCCL_TRY_IN_GROUP(ctx, expr)                                                                              \
+    do {                                                                                                          \
+        ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != ncclSuccess) {                                                                                  \
+            (void)nccl->GroupEnd();                                                                               \
+            return set_error(ctx, PT_ERR_COMM, std::string(#expr) + ": " + nccl->GetErrorString(r_));             \
+        }                                                                                                         \
+    } while (0)
+
 static uint32_t rows_of_member(uint32_t height, uint32_t world, uint32_t rank) {
     return rank < height ? (height - rank + world - 1) / world : 0u;
 }
@@ -1480,12 +1628,12 @@ static int group_gather(pt_ctx *const *m, int n_local, int root) {
             for (int r = 0; r < world; ++r) {
                 if (r == root) continue;
                 const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)r) * w * 4;
-                if (count) NCCL_TRY(c, nccl->Recv((float *)c->d_stage[0] + offset, count, ncclFloat, r, c->comm, c->stream));
+                if (count) NCCL_TRY_IN_GROUP(c, nccl->Recv((float *)c->d_stage[0] + offset, count, ncclFloat, r, c->comm, c->stream));
                 offset += count;
             }
         } else {
             const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)c->group_rank) * w * 4;
-            if (count) NCCL_TRY(c, nccl->Send(c->d_stage[0], count, ncclFloat, root, c->comm, c->stream));
+            if (count) NCCL_TRY_IN_GROUP(c, nccl->Send(c->d_stage[0], count, ncclFloat, root, c->comm, c->stream));
         }
     }
     NCCL_TRY(first, nccl->GroupEnd());
@@ -1538,8 +1686,11 @@ int pt_group_join_local(pt_ctx *const *ctxs, int n) {
     NCCL_TRY(ctxs[0], nccl->GetUniqueId(&uid));
     NCCL_TRY(ctxs[0], nccl->GroupStart());
     for (int k = 0; k < n; ++k) {
-        HIP_TRY(ctxs[k], hipSetDevice(ctxs[k]->device));
-        NCCL_TRY(ctxs[k], nccl->CommInitRank(&ctxs[k]->comm, n, uid, k));
+        if (hipError_t e = hipSetDevice(ctxs[k]->device); e != hipSuccess) {
+            (void)nccl->GroupEnd();
+            return set_error(ctxs[k], PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        }
+        NCCL_TRY_IN_GROUP(ctxs[k], nccl->CommInitRank(&ctxs[k]->comm, n, uid, k));
     }
     NCCL_TRY(ctxs[0], nccl->GroupEnd());
     for (int k = 0; k < n; ++k) {
@@ -1605,8 +1756,8 @@ int pt_group_loopback(pt_ctx *ctx) {
     for (uint32_t y = 1; y < h; y += 2)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_image + (size_t)y * w * 4, 0xff, (size_t)w * 4 * sizeof(float), ctx->stream));
     NCCL_TRY(ctx, nccl->GroupStart());
-    NCCL_TRY(ctx, nccl->Send(ctx->d_stage[1], count, ncclFloat, 0, ctx->comm, ctx->stream));
-    NCCL_TRY(ctx, nccl->Recv(ctx->d_stage[0], count, ncclFloat, 0, ctx->comm, ctx->stream));
+    NCCL_TRY_IN_GROUP(ctx, nccl->Send(ctx->d_stage[1], count, ncclFloat, 0, ctx->comm, ctx->stream));
+    NCCL_TRY_IN_GROUP(ctx, nccl->Recv(ctx->d_stage[0], count, ncclFloat, 0, ctx->comm, ctx->stream));
     NCCL_TRY(ctx, nccl->GroupEnd());
     hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(ctx, (uint64_t)w * h)), dim3(kBlock), 0, ctx->stream,
                        (float4 *)ctx->d_image, w, h, 2u, 0u, (const float4 *)ctx->d_stage[0]);
