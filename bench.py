@@ -186,6 +186,8 @@ def main():
     # a realtime frame traces the pixels that pass the 80 % skip (src/trace.rs:144): 20 % of them on average
     paths_per_step = float(W) * H * args.spp * (0.2 if args.realtime else 1.0)
 
+    gather_note = []
+
     def timed_leg(flags):
         """W warm-up steps, then K steps between barriers, max over ranks: (seconds, stats, image tensor, ctx)."""
         ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight, flags=flags)
@@ -196,13 +198,32 @@ def main():
         rows, pack, gather_list = None, None, None
         if world > 1:
             if args.gather == "capi":
-                ident = torch.zeros(pt.PT_GROUP_ID_BYTES, dtype=torch.uint8, device=image.device)
-                if rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(pt.group_unique_id()), dtype=torch.uint8))
-                dist.broadcast(ident, src=0)
-                ctx.group_join(ident.cpu().numpy().tobytes(), rank, world)
-                rows = ctx.group_rows()
-            else:
+                # A failure that every rank sees alike (RCCL not loadable beside PyTorch's copy, an id it rejects) falls
+                # back to the torch.distributed gather instead of losing the run; the line then says so.
+                ok = torch.ones(1, dtype=torch.int32, device=image.device)
+                try:
+                    ident = torch.zeros(pt.PT_GROUP_ID_BYTES, dtype=torch.uint8, device=image.device)
+                    if rank == 0:
+                        ident.copy_(torch.frombuffer(bytearray(pt.group_unique_id()), dtype=torch.uint8))
+                except pt.PtError as e:
+                    ok.zero_()
+                    gather_note.append(str(e))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()):
+                    dist.broadcast(ident, src=0)
+                    try:
+                        ctx.group_join(ident.cpu().numpy().tobytes(), rank, world)
+                    except pt.PtError as e:
+                        ok.zero_()
+                        gather_note.append(str(e))
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()):
+                    rows = ctx.group_rows()
+                else:
+                    ctx.group_leave()
+                    args.gather = "torch"
+                    gather_note.append("fell back to torch.distributed.gather")
+            if args.gather != "capi":
                 rows = tiles.rows_for(rank, world)
                 pack = torch.zeros((tiles.max_rows(world, H), W, 4), dtype=torch.float32, device=image.device)
                 if rank == 0:
@@ -326,6 +347,7 @@ def main():
                             f"{'realtime progressive frames (80 % pixel skip), ' if args.realtime else ''}"
                             f"{'one tile' if world == 1 else f'rows interleaved over {world} GPUs + RCCL gather ({args.gather})'}",
                 "world_size": world,
+                "gather_note": "; ".join(gather_note) or None,
                 "paths_in_flight": args.paths_in_flight,
                 "frames_per_s": (args.steps / elapsed) if args.realtime else None,
                 "present": args.present,
