@@ -272,3 +272,26 @@ def test_accel_tree_invariants(name, param):
     assert 1 <= info["n_nodes"] < info["n_prims"]
     assert info["depth"] < 28
 
+
+
+@pytest.mark.parametrize("seed,n_prims", [(101, 6), (105, 24), (203, 90), (323, 1000)])
+def test_accel_tree_invariants_of_random_compositions(seed, n_prims):
+    """The same invariants on scenes assembled through the builder API from a seed (the compositions the device
+    parity test traces): wrapped boxes, rects and spheres, media in wrapped boundaries, moving spheres."""
+    from test_gpu_fuzz_scenes import random_composition
+
+    scene = random_composition(seed, n_prims)
+    info = scene.accel_info()
+    flat = scene.flatten_info()
+    assert n_prims <= info["n_prims"] <= flat["n_leaves"]
+    assert 1 <= info["n_nodes"] < info["n_prims"] and info["depth"] < 28
+    assert flat["max_frame_depth"] == 0  # every wrapper chain ends at a primitive: no wrapped subtree
+
+
+def test_scene_wide_primitives_sit_under_the_root():
+    """Primitives whose box spans the scene (the fog around the final scene, the ground sphere of random_scene) are the
+    root's first child; the tree's invariants hold with them there, and the depth does not grow with their number of
+    neighbours."""
+    for name in ("final_book_two", "random_scene"):
+        info = ptgpu.Scene.named(name, 1.0).accel_info()
+        assert info["depth"] <= 16, (name, info)
