@@ -258,8 +258,7 @@ enum pt_pass_form {
     PT_PASS_PER_BOUNCE = 1,       /* ray generation, then an extend and a shade launch per bounce */
     PT_PASS_PERSISTENT = 3,       /* primitive-list scenes: ray generation + one trace-and-shade launch over queue tiles */
     PT_PASS_PATH_POOL = 4,        /* primitive-list scenes, offline: one launch, paths stay in registers */
-    PT_PASS_TREE_POOL = 5,        /* tree scenes, offline: one launch, traversal and shading inside the wave */
-    PT_PASS_PATH_POOL_SORTED = 6  /* the path pool with the paths of a workgroup regrouped by vertex kind every round */
+    PT_PASS_TREE_POOL = 5         /* tree scenes, offline: one launch, traversal and shading inside the wave */
 };
 
 /* No reference counterpart (the crate owns no device); allocates the per-GPU state. */

@@ -195,7 +195,7 @@ class RenderArgs(C.Structure):
     ]
 
 
-PT_PASS_NONE, PT_PASS_PER_BOUNCE, PT_PASS_PERSISTENT, PT_PASS_PATH_POOL, PT_PASS_TREE_POOL, PT_PASS_PATH_POOL_SORTED = 0, 1, 3, 4, 5, 6
+PT_PASS_NONE, PT_PASS_PER_BOUNCE, PT_PASS_PERSISTENT, PT_PASS_PATH_POOL, PT_PASS_TREE_POOL = 0, 1, 3, 4, 5
 
 
 class Stats(C.Structure):

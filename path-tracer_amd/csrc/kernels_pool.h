@@ -196,172 +196,6 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The path pool with its lanes regrouped every round. In k_path_pool a wave shades whatever its 64 paths have hit: about
-// half of its lanes stand on a diffuse surface, a third on glass, the rest end, and the wave runs every branch it
-// holds, the dearest of them (direction sampling and the mixture pdf of a diffuse vertex) at half its lanes. Here the
-// four waves of a workgroup exchange their paths through LDS after the list walk, ordered by what the vertex will do
-// (diffuse / glass / other / free slot), so that a wave shades mostly one kind; free slots end up side by side, and
-// the lanes that get them start the pass's next paths in place (they join the next walk). A path is the same
-// whichever lane carries it (its draws are keyed by pixel and sample; its radiance sum is formed vertex by vertex in
-// memory, in the same order), so the image is bit-identical to the other forms. Two barriers per round; the groups are
-// dealt to the waves in rotation so that the four SIMDs of a CU see the same mix over time.
-// ------------------------------------------------------------------------------------------------------------
-struct SortLds {
-    LdsLeaf leaves[kLdsLeaves];
-    double f[11][kBlock];  // origin, direction, throughput, time, hit distance
-    uint64_t key[kBlock];
-    uint32_t u[4][kBlock]; // path id, draws made, depth (kIdle: a free slot), hit id
-    uint32_t cnt[4][kWavesPerBlock]; // [group][wave]: lanes of the wave in the group, this round
-    uint32_t ids[2][4];    // [round parity]: next path id of the workgroup's chunk, its end, 1 once the pass has no more
-};
-template <int TEX, int FUSE>
-__global__ __launch_bounds__(kBlock, pool_waves(false, FUSE)) void k_path_pool_sorted(SceneView sv, const PoolConsts *consts, uint32_t n,
-                                                                      uint32_t max_depth, double *lx, double *ly,
-                                                                      double *lz, uint32_t *counts, uint32_t flags,
-                                                                      uint32_t chunk) {
-    static_assert(kWavesPerBlock == 4, "the group tables below are written for four waves");
-    __shared__ SortLds S;
-    constexpr uint32_t kIdle = 0xffffffffu;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    {
-        constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
-        const double *src = (const double *)sv.leaves;
-        for (int k = tid; k < sv.n_leaves * kWords; k += kBlock) ((double *)&S.leaves[k / kWords].l)[k % kWords] = src[k];
-        if (tid == 0) { // the workgroup's first chunk of path ids
-            const uint32_t first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
-            S.ids[0][0] = min(first, n);
-            S.ids[0][1] = min(min(first, n) + chunk, n);
-            S.ids[0][2] = first >= n ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-    bool has = false;
-    D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), beta = d3(0.0, 0.0, 0.0);
-    double time = 0.0;
-    uint64_t pkey = 0;
-    uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
-    for (uint32_t round = 0;; ++round) {
-        segments += (uint32_t)__popcll(__ballot(has));
-        double ht;
-        int32_t id;
-        extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along
-        // the group of this lane's vertex
-        uint32_t grp = 3u;
-        if (has) {
-            grp = 2u;
-            if (id >= 0 && depth < max_depth) {
-                const int32_t mk = S.leaves[id & 0x0fffffff].l.mat_kind;
-                grp = (mk == PT_M_LAMBERTIAN || mk == PT_M_ISOTROPIC) ? 0u : (mk == PT_M_DIELECTRIC ? 1u : 2u);
-            }
-        }
-        const unsigned long long m0 = __ballot(grp == 0u), m1 = __ballot(grp == 1u), m2 = __ballot(grp == 2u), m3 = __ballot(grp == 3u);
-        if (lane < 4u) {
-            const unsigned long long m = lane == 0u ? m0 : (lane == 1u ? m1 : (lane == 2u ? m2 : m3));
-            S.cnt[lane][wv] = (uint32_t)__popcll(m);
-        }
-        __syncthreads(); // every wave's counts are in; nobody still reads last round's exchange
-        const uint32_t par = round & 1u;
-        uint32_t base[4], mine[4]; // first slot of a group; lanes of earlier waves in it
-        {
-            uint32_t run = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint32_t c0 = S.cnt[g][0], c1 = S.cnt[g][1], c2 = S.cnt[g][2], c3 = S.cnt[g][3];
-                base[g] = run;
-                mine[g] = wv == 0u ? 0u : (wv == 1u ? c0 : (wv == 2u ? c0 + c1 : c0 + c1 + c2));
-                run += c0 + c1 + c2 + c3;
-            }
-        }
-        const uint32_t n_free = kBlock - base[3];
-        const uint32_t cur = S.ids[par][0], end = S.ids[par][1], exhausted = S.ids[par][2];
-        const uint32_t take = min(n_free, end - cur);
-        if (n_free == kBlock && end == cur && exhausted) break; // nothing in flight, nothing left to start (every lane sees the same)
-        if (tid == 0) { // the chunk as the next round will find it
-            uint32_t ncur = cur + take, nend = end, nex = exhausted;
-            if (ncur >= nend && !nex) {
-                const uint32_t first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
-                nex = first >= n ? 1u : 0u;
-                ncur = min(first, n);
-                nend = min(ncur + chunk, n); // chunk is far below 2^32 - n
-            }
-            S.ids[par ^ 1u][0] = ncur;
-            S.ids[par ^ 1u][1] = nend;
-            S.ids[par ^ 1u][2] = nex;
-        }
-        const unsigned long long mm = grp == 0u ? m0 : (grp == 1u ? m1 : (grp == 2u ? m2 : m3));
-        const uint32_t slot = (grp == 0u ? base[0] + mine[0] : (grp == 1u ? base[1] + mine[1] : (grp == 2u ? base[2] + mine[2] : base[3] + mine[3]))) +
-                              (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-        const uint32_t rot = (round & 3u) * 64u; // which wave gets which part of the order
-        const uint32_t at = (slot + rot) & (kBlock - 1u);
-        if (has) {
-            S.f[0][at] = o.x; S.f[1][at] = o.y; S.f[2][at] = o.z;
-            S.f[3][at] = d.x; S.f[4][at] = d.y; S.f[5][at] = d.z;
-            S.f[6][at] = beta.x; S.f[7][at] = beta.y; S.f[8][at] = beta.z;
-            S.f[9][at] = time; S.f[10][at] = ht;
-            S.key[at] = pkey;
-            S.u[0][at] = pid; S.u[1][at] = rn; S.u[3][at] = (uint32_t)id;
-        }
-        S.u[2][at] = has ? depth : kIdle;
-        __syncthreads();
-        const uint32_t q = (tid - rot) & (kBlock - 1u); // this lane's place in the order
-        const bool live = q < base[3];
-        const bool fresh = !live && q - base[3] < take;
-        if (live) {
-            o = d3(S.f[0][tid], S.f[1][tid], S.f[2][tid]);
-            d = d3(S.f[3][tid], S.f[4][tid], S.f[5][tid]);
-            beta = d3(S.f[6][tid], S.f[7][tid], S.f[8][tid]);
-            time = S.f[9][tid]; ht = S.f[10][tid];
-            pkey = S.key[tid];
-            pid = S.u[0][tid]; rn = S.u[1][tid]; depth = S.u[2][tid]; id = (int32_t)S.u[3][tid];
-        }
-        has = live;
-        if (live) {
-            const int32_t li = id < 0 ? 0 : (id & 0x0fffffff);
-            D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
-            const bool alive = shade_vertex<false, TEX, RAD_RETURN>(sv, S.leaves[li].l, o, d, time, beta, pkey, pid, rn, ht, id,
-                                                                    depth, max_depth, flags, lx, ly, lz, no, nd, nbeta, &c);
-            // the per-path sum of the other forms, kept in memory: the first vertex is stored, later ones are added unless
-            // zero. One lane holds a path at a time, and the barriers above order one holder's accesses before the next's.
-            if (depth == 0) {
-                lx[pid] = c.x; ly[pid] = c.y; lz[pid] = c.z;
-            } else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) {
-                unsafeAtomicAdd(&lx[pid], c.x); unsafeAtomicAdd(&ly[pid], c.y); unsafeAtomicAdd(&lz[pid], c.z);
-            }
-            o = no; d = nd; beta = nbeta;
-            depth += 1;
-            has = alive;
-        }
-        if (fresh) { // a free slot takes the next path of the pass: camera sample (src/trace.rs:153-156, src/camera.rs:53-59)
-            const PoolConsts *pc = consts;
-            asm volatile("" : "+s"(pc)); // keeps the loads below in this block
-            const CameraDev cam = pc->cam;
-            const PassParams pp = pc->pp;
-            pid = cur + (q - base[3]);
-            const uint32_t p = pid % pp.cpix, smp = pid / pp.cpix;
-            const uint32_t i = pp.cx0 + p % pp.cw, jy = pp.cy0 + (p / pp.cw) * pp.row_step;
-            const uint64_t pixel = (uint64_t)jy * pp.width + i;
-            Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + smp), 0};
-            double random = g.next();
-            const double u = ((double)i + random) / (double)pp.width;
-            random = g.next();
-            const double v = ((double)jy + random) / (double)pp.height;
-            const D3 rd = random_in_unit_disk(g) * cam.lens_radius;
-            const D3 offset = cam.u * rd.x + cam.v * rd.y;
-            time = cam.time0 + g.next() * (cam.time1 - cam.time0);
-            d = cam.lower_left_corner + cam.horizontal * u + cam.vertical * v - cam.origin - offset;
-            o = cam.origin + offset;
-            beta = d3(1.0, 1.0, 1.0);
-            pkey = g.key;
-            rn = g.n;
-            depth = 0;
-            has = true;
-        }
-    }
-    if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments); // as in k_path_pool
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // The path pool for scenes that are traced through the SAH tree: one launch per offline pass, a path in one lane's
 // registers from camera sample to last vertex, no queues. A lane is free, on an inner node, on a leaf, or waiting
 // with a finished traversal. Every round steps the traversing lanes (inner nodes first, then leaves, as in

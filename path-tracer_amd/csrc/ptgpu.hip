@@ -153,7 +153,6 @@ struct pt_ctx {
     std::deque<PoolConsts> h_pool_consts; // host copies of the passes in flight (cleared at every stream synchronisation of a render)
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
-    bool pool_sorted = false;     // ... whose workgroups regroup their paths by vertex kind every round (k_path_pool_sorted)
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
     uint32_t pool_chunk = 512;    // path ids a wave takes from the pass's counter at a time
@@ -525,17 +524,6 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             if (xpool) {
                 if (media) launch(k_path_pool<kTex, 2, true>);
                 else launch(k_path_pool<kTex, 1, true>);
-            } else if (ctx->pool_sorted) {
-                // a chunk belongs to a workgroup here, not to a wave
-                const uint32_t fair_wg = (n / (grid * 4u) + 255u) & ~255u;
-                const uint32_t chunk_wg = std::max(256u, std::min(ctx->pool_chunk * kWavesPerBlock, fair_wg));
-                auto launch_sorted = [&](auto kernel) {
-                    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, (const PoolConsts *)ctx->d_pool_consts, n,
-                                       pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
-                                       chunk_wg);
-                };
-                if (media) launch_sorted(k_path_pool_sorted<kTex, 2>);
-                else launch_sorted(k_path_pool_sorted<kTex, 1>);
             } else if (media) launch(k_path_pool<kTex, 2>);
             else launch(k_path_pool<kTex, 1>);
         });
@@ -693,8 +681,7 @@ bool apply_tuning(pt_ctx *ctx, const pt_tuning &t) {
     case PT_PASS_PERSISTENT: // list scenes through the persistent queue form, offline passes included
         ctx->path_pool = false;
         break;
-    case PT_PASS_PATH_POOL_SORTED: ctx->pool_sorted = true; break;
-    case PT_PASS_PATH_POOL: ctx->pool_sorted = false; break;
+    case PT_PASS_PATH_POOL:
     case PT_PASS_TREE_POOL: break; // what offline passes use anyway
     default: return false;
     }
