@@ -1,0 +1,43 @@
+// The fast-mode path pool over primitive lists without media, k_path_pool<TEX, 1, false> (kernels_pool.h): the kernel that
+// traces the Cornell box. It is the one kernel of the library whose time is the issue rate of the FP64 pipe at a register
+// budget it just fits (128 VGPRs, a few spills), and it is compiled here, apart from the others, under the scheduling
+// strategy that keeps register pressure lowest (the Makefile passes -mllvm -amdgpu-sched-strategy=iterative-minreg for
+// this file): +2 to +3 % on the Cornell box. The same flag costs the tree pool 3 to 34 %, exact mode 2 % and the variant with
+// media inside 2 %, which is why those stay in ptgpu.hip under the default scheduler. Same sources, same arithmetic (-ffp-contract=off in both).
+#include <hip/hip_runtime.h>
+
+#include "accel.h"
+#include "pool_list.h"
+#include "pt_device.h"
+
+using namespace ptdev;
+
+namespace {
+
+#include "kernels_queue.h"
+#include "kernels_extend.h"
+#include "kernels_shade.h"
+#include "kernels_pool.h"
+
+template <int TEX>
+void launch_tex(uint32_t grid, hipStream_t stream, const SceneView &sv, const PoolConsts *consts, uint32_t n,
+                uint32_t max_depth, double *lx, double *ly, double *lz, uint32_t *counts, uint32_t flags, uint32_t refill,
+                uint32_t chunk) {
+    hipLaunchKernelGGL((k_path_pool<TEX, 1, false>), dim3(grid), dim3(kBlock), 0, stream, sv, consts, n, max_depth, lx, ly, lz,
+                       counts, flags, refill, chunk);
+}
+
+} // namespace
+
+namespace ptdev {
+
+void launch_path_pool_list(int tex, uint32_t grid, hipStream_t stream, const SceneView &sv, const void *consts, uint32_t n,
+                           uint32_t max_depth, double *lx, double *ly, double *lz, uint32_t *counts, uint32_t flags,
+                           uint32_t refill, uint32_t chunk) {
+    const PoolConsts *pc = (const PoolConsts *)consts;
+    if (tex == 0) launch_tex<0>(grid, stream, sv, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
+    else if (tex == 1) launch_tex<1>(grid, stream, sv, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
+    else launch_tex<2>(grid, stream, sv, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
+}
+
+} // namespace ptdev

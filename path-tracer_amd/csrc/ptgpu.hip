@@ -31,6 +31,7 @@
 
 #include "accel.h"
 #include "flatten.h"
+#include "pool_list.h"
 #include "pt_device.h"
 
 using namespace ptdev;
@@ -525,8 +526,11 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                 if (media) launch(k_path_pool<kTex, 2, true>);
                 else launch(k_path_pool<kTex, 1, true>);
             } else if (media) launch(k_path_pool<kTex, 2>);
-            else launch(k_path_pool<kTex, 1>);
         });
+        // fast mode without media: compiled in pool_list.hip, under a scheduling strategy of its own
+        if (!xpool && !media)
+            launch_path_pool_list(ctx->tex, grid, st, v, ctx->d_pool_consts, n, pp.max_depth, ctx->d_l[0], ctx->d_l[1],
+                                  ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill, chunk);
         HIP_TRY(ctx, mark());
     }
     if (tree) {
