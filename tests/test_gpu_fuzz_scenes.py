@@ -133,3 +133,54 @@ def test_random_composition_matches_the_oracle(any_ctx, seed, n_prims):
         close = np.isclose(got, ref, rtol=1e-5, atol=1e-7) | ~finite
         assert nan_same >= 0.99, f"NaN masks agree on {nan_same:.4f}"
         assert close.mean() >= (0.995 if exact else 0.98), f"{close.mean():.4f} of channels agree"
+
+
+@pytest.mark.parametrize("seed,n_prims", [(102, 11), (105, 24), (202, 40), (320, 128)])
+def test_random_composition_realtime_frames_tiles_and_rows(any_ctx, seed, n_prims):
+    """On the same compositions: progressive realtime frames (80 % pixel skip, running blend, src/trace.rs:144-177)
+    against the oracle; a tile of the image and the interleaved rows of a group of three against the whole render."""
+    ctx, exact = any_ctx
+    scene = random_composition(seed, n_prims)
+    desc = scene.desc()
+    ctx.upload(scene)
+    w, h = 48, 36
+    ctx.reset()
+    ref = np.zeros((h, w, 4), dtype=np.float32)
+    counts = np.zeros((h, w), dtype=np.uint32)
+    for frame in range(5):
+        ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=frame)
+        ob.render(desc, scene.camera, w, h, 1, 10, seed=ctx.seed, mode=1, frame=frame, threads=4, image=ref, counts=counts)
+    got = ctx.readback()
+    touched = counts > 0
+    assert 0.45 < touched.mean() < 0.9  # 1 - 0.8^5 = 0.67
+    assert (got[~touched][..., :3] == 0).all()
+    close = np.isclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6, equal_nan=True)
+    assert close.mean() >= (0.995 if exact else 0.98)
+    # offline: parts against the whole
+    ctx.reset()
+    ctx.render(w, h, 3, 12)
+    whole = ctx.readback()
+    x0, y0, x1, y1 = 5, 3, 41, 30
+    for phase in range(3):
+        ctx.reset()
+        ctx.render(w, h, 3, 12, tile=(x0, y0, x1, y1), rows=(3, phase))
+        part = ctx.readback()
+        mask = np.zeros((h, w), dtype=bool)
+        mask[y0 + phase:y1:3, x0:x1] = True
+        assert np.array_equal(part[mask], whole[mask], equal_nan=True)
+        assert not np.nan_to_num(part[~mask]).any()
+
+
+@pytest.mark.parametrize("seed,n_prims", [(103, 17), (203, 90)])
+def test_random_composition_pass_forms_agree(seed, n_prims):
+    """The one-launch pool forms and a launch per stage and bounce trace the same paths on compositions too."""
+    scene = random_composition(seed, n_prims)
+    images = []
+    for tuning in ({}, {"pass_form": ptgpu.PT_PASS_PER_BOUNCE}, {"pool_chunk": 64, "pool_refill": 1, "tree_refill": 1}):
+        ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 18, **tuning)
+        ctx.upload(scene)
+        ctx.render(96, 64, 4, 20)
+        images.append(ctx.readback())
+        ctx.close()
+    assert np.array_equal(images[0], images[1], equal_nan=True)
+    assert np.array_equal(images[0], images[2], equal_nan=True)
