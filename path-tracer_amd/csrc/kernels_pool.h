@@ -34,13 +34,22 @@ struct PoolLds {
 constexpr int pool_waves(bool exact, int fuse) { return exact ? PT_EXACT_POOL_WAVES : (fuse == 2 ? PT_MEDIA_POOL_WAVES : PT_SHADE_WAVES); }
 // X: exact mode. The walk is the wave-uniform scan of the reference's own threaded tree (every box test, the
 // reference's order), the arithmetic is M<true>'s; sv.ops is then the full stream, not the fused list.
-template <int TEX, int FUSE, bool X = false>
+// RT: a realtime frame (src/trace.rs:144-146: four of five pixels are skipped, by a draw keyed on seed, frame and pixel).
+// The path ids of a frame cover every pixel; before a wave makes its next 64 camera samples it evaluates the skip draw
+// of 64 ids at a time with all its lanes and collects the ids that survive, so that no sample is made for a pixel the
+// frame skips.
+template <int TEX, int FUSE, bool X = false, bool RT = false>
 __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
                                                                       uint32_t max_depth, double *lx, double *ly,
                                                                       double *lz, uint32_t *counts, uint32_t flags,
                                                                       uint32_t refill_arg, uint32_t chunk) {
     __shared__ PoolLds S;
-    const uint32_t refill_at = min(max(refill_arg, 1u), 64u); // outside [1, 64] the loops below could not end
+    __shared__ uint32_t live[RT ? kWavesPerBlock : 1][128]; // RT: surviving path ids of the wave, not yet made into samples
+    uint32_t live_n = 0;
+    const uint32_t refill_at = min(max(refill_arg & 0xffu, 1u), 64u); // outside [1, 64] the loops below could not end
+    // RT: the launch has a chunk for every wave (bit 31 of refill_arg): wave k takes chunk k and no counter is involved. A
+    // frame is short, and 4 096 waves queueing at one atomic address were a sixth of it.
+    const bool static_chunks = (refill_arg >> 31) != 0u;
     {
         constexpr int kWords = (int)(sizeof(DevLeaf) / sizeof(double));
         const double *src = (const double *)sv.leaves;
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
     // launch and left out of the segment sum): a wave takes the next chunk when its current one is used up, so every
     // wave stays full until the pass itself runs out of paths.
     uint32_t cur = 0, end = 0, stash_n = 0;
-    bool exhausted = false;
+    bool exhausted = false, started = false;
     bool has = false;
     D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), beta = d3(0.0, 0.0, 0.0), sum = d3(0.0, 0.0, 0.0);
     double time = 0.0;
@@ -70,26 +79,62 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (n_idle < refill_at) break;
             if (stash_n == 0) {
-                if (cur >= end && !exhausted) {
-                    uint32_t first = 0;
-                    if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
-                    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-                    exhausted = first >= n;
-                    cur = min(first, n);
-                    end = min(cur + chunk, n); // chunk is far below 2^32 - n
-                }
-                if (cur >= end) { // the pass has no more paths to start
-                    drained = n_idle == 64;
-                    break;
-                }
-                // the next (up to) 64 camera samples, one per lane, parked in LDS
+                auto next_chunk = [&]() { // the wave's next chunk of path ids, when the current one is used up
+                    if (cur >= end && !exhausted) {
+                        uint32_t first = 0;
+                        if (RT && static_chunks) { // its one chunk, then none
+                            first = started ? n : min((blockIdx.x * kWavesPerBlock + wv) * chunk, n);
+                            started = true;
+                        } else if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
+                        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                        exhausted = first >= n;
+                        cur = min(first, n);
+                        end = min(cur + chunk, n); // chunk is far below 2^32 - n
+                    }
+                };
                 const PoolConsts *pc = consts;
                 asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+                uint32_t m, id;
+                if constexpr (RT) {
+                    const PassParams ppr = pc->pp;
+                    while (live_n < 64u) { // skip draws of the next 64 ids; the survivors join the list (at most 64 + 64)
+                        next_chunk();
+                        if (cur >= end) break;
+                        const uint32_t h = cur + lane;
+                        bool alive = false;
+                        if (h < end) {
+                            const uint32_t p = h % ppr.cpix;
+                            const uint64_t pixel = (uint64_t)(ppr.cy0 + (p / ppr.cw) * ppr.row_step) * ppr.width + (ppr.cx0 + p % ppr.cw);
+                            alive = !(pixel_skip_draw(ppr.seed, ppr.frame, pixel) < 0.8); // src/trace.rs:144
+                        }
+                        const unsigned long long mask = __ballot(alive);
+                        if (alive) live[wv][live_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = h;
+                        live_n += (uint32_t)__popcll(mask);
+                        cur = min(cur + 64u, end);
+                    }
+                    if (live_n == 0) { // the frame has no more paths to start
+                        drained = n_idle == 64;
+                        break;
+                    }
+                    wave_lds_fence();
+                    m = min(64u, live_n);
+                    id = lane < m ? live[wv][live_n - m + lane] : 0u;
+                    live_n -= m;
+                    wave_lds_fence(); // the slots just read may be written again
+                } else {
+                    next_chunk();
+                    if (cur >= end) { // the pass has no more paths to start
+                        drained = n_idle == 64;
+                        break;
+                    }
+                    m = min(64u, end - cur);
+                    id = cur + lane;
+                    cur += m;
+                }
+                // the next (up to) 64 camera samples, one per lane, parked in LDS
                 const CameraDev cam = pc->cam;
                 const PassParams pp = pc->pp;
-                const uint32_t m = min(64u, end - cur);
                 const bool fresh = lane < m;
-                const uint32_t id = cur + lane;
                 uint32_t i = 0, jy = 0, smp = 0;
                 uint64_t pixel = 0;
                 if (fresh) {
@@ -120,7 +165,6 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
                     S.cam_pid[wv][k] = id;
                 }
                 stash_n = (uint32_t)__popcll(made);
-                cur += m;
             }
             const uint32_t take = min(n_idle, stash_n);
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -221,7 +265,10 @@ template <int TEX, bool MEDIA, bool RT = false>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
-                                                                      uint32_t flags, uint32_t tuning, uint32_t chunk) {
+                                                                      uint32_t flags, uint32_t tuning, uint32_t chunk_arg) {
+    const uint32_t chunk = chunk_arg & 0x7fffffffu;
+    const bool static_chunks = (chunk_arg >> 31) != 0u; // RT: one chunk per wave, dealt by wave index
+    bool started = false;
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
     __shared__ uint32_t live[RT ? kWavesPerBlock : 1][64]; // RT: surviving path ids of the wave, not yet taken
     uint32_t live_n = 0;
@@ -300,7 +347,10 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
     auto next_chunk = [&]() {
         if (cur >= end && !exhausted) {
             uint32_t first = 0;
-            if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
+            if (RT && static_chunks) { // the launch has a chunk for every wave: wave k takes chunk k, no counter (see k_path_pool)
+                first = started ? n : min((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * chunk, n);
+                started = true;
+            } else if (lane == 0) first = atomicAdd(&counts[(size_t)(max_depth + 1) * kShards], chunk);
             first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
             exhausted = first >= n;
             cur = min(first, n);

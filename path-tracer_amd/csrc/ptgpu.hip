@@ -451,7 +451,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // kernels). Realtime frames hold 0.4 M paths after the 80 % pixel skip; through the pool they measured 16 %
     // slower than through the persistent queue form below (four of five generated samples are skipped), which in
     // turn measured +53 % at 2^20 paths, +13 % at 2^22, -3 % at 2^24 against a launch per bounce.
-    const bool pool = fused && ctx->path_pool && !realtime;
+    const bool pool = fused && ctx->path_pool; // realtime frames too: the waves evaluate the pixel skip before they make samples
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
                        ctx->view.n_leaves <= kLdsLeaves;
@@ -505,8 +505,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const uint32_t resident = (uint32_t)ctx->n_cu * pool_waves(xpool, media ? 2 : 1) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         // a small pass is cut into at least four chunks per wave so that the waves finish together
-        const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
+        // (a realtime frame's ids are mostly skipped pixels: one chunk per wave, or the chunk counter, one address for the
+        // whole chip, is what the frame waits for)
+        const uint32_t fair = (n / (grid * kWavesPerBlock * (realtime ? 1u : 4u)) + 63u) & ~63u;
         const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        // realtime: when every wave of the launch has a chunk of its own, the chunks are dealt by wave index
+        const uint32_t static_bit = (realtime && (uint64_t)chunk * grid * kWavesPerBlock >= n) ? 0x80000000u : 0u;
         SceneView v = ctx->view;
         v.ops = (const DevOp *)ctx->d_ops_fused;
         v.n_traversal_ops = ctx->n_fused_ops;
@@ -517,7 +521,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, (const PoolConsts *)ctx->d_pool_consts, n,
                                pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
-                               ctx->pool_refill, chunk);
+                               ctx->pool_refill | static_bit, chunk);
         };
         if (xpool) v = ctx->view; // the reference's own tree
         with_tex(ctx->tex, [&](auto T) {
@@ -525,20 +529,24 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
             if (xpool) {
                 if (media) launch(k_path_pool<kTex, 2, true>);
                 else launch(k_path_pool<kTex, 1, true>);
-            } else if (media) launch(k_path_pool<kTex, 2>);
+            } else if (media) {
+                if (realtime) launch(k_path_pool<kTex, 2, false, true>);
+                else launch(k_path_pool<kTex, 2>);
+            }
         });
         // fast mode without media: compiled in pool_list.hip, under a scheduling strategy of its own
         if (!xpool && !media)
-            launch_path_pool_list(ctx->tex, grid, st, v, ctx->d_pool_consts, n, pp.max_depth, ctx->d_l[0], ctx->d_l[1],
-                                  ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill, chunk);
+            launch_path_pool_list(ctx->tex, realtime, grid, st, v, ctx->d_pool_consts, n, pp.max_depth, ctx->d_l[0], ctx->d_l[1],
+                                  ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill | static_bit, chunk);
         HIP_TRY(ctx, mark());
     }
     if (tree) {
         const uint32_t tiles = (n + 63u) / 64u;
         const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
-        const uint32_t fair = (n / (grid * kWavesPerBlock * 4u) + 63u) & ~63u;
-        const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        const uint32_t fair = (n / (grid * kWavesPerBlock * (realtime ? 1u : 4u)) + 63u) & ~63u; // as for the path pool
+        uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        if (realtime && (uint64_t)chunk * grid * kWavesPerBlock >= n) chunk |= 0x80000000u; // chunks dealt by wave index
         HIP_TRY(ctx, send_pool_consts());
         // big trees (a million spheres: a node fetch is an L2 miss more often than not) turn to their leaves earlier: the
         // lanes left on inner nodes would each wait a full memory round trip per step (one million spheres +3 %; the
