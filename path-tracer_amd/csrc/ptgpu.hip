@@ -154,6 +154,7 @@ struct pt_ctx {
     std::deque<PoolConsts> h_pool_consts; // host copies of the passes in flight (cleared at every stream synchronisation of a render)
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
+    uint32_t pool_rt_min = 1u << 19; // realtime frames of list scenes: path ids from which the pool is used (below: the queue form)
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
     uint32_t pool_chunk = 512;    // path ids a wave takes from the pass's counter at a time
@@ -451,7 +452,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // kernels). Realtime frames hold 0.4 M paths after the 80 % pixel skip; through the pool they measured 16 %
     // slower than through the persistent queue form below (four of five generated samples are skipped), which in
     // turn measured +53 % at 2^20 paths, +13 % at 2^22, -3 % at 2^24 against a launch per bounce.
-    const bool pool = fused && ctx->path_pool; // realtime frames too: the waves evaluate the pixel skip before they make samples
+    // Realtime frames too (the waves evaluate the pixel skip before they make samples), from half a million pixels up:
+    // 1080p +46 %, 2160p +59 % against the queue form below; a 640 x 360 frame is all launch latency and runs 18 % faster
+    // through the queue form.
+    const bool pool = fused && ctx->path_pool && (!realtime || n >= ctx->pool_rt_min);
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
                        ctx->view.n_leaves <= kLdsLeaves;
@@ -507,8 +511,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         // a small pass is cut into at least four chunks per wave so that the waves finish together
         // (a realtime frame's ids are mostly skipped pixels: one chunk per wave, or the chunk counter, one address for the
         // whole chip, is what the frame waits for)
-        const uint32_t fair = (n / (grid * kWavesPerBlock * (realtime ? 1u : 4u)) + 63u) & ~63u;
-        const uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        const uint32_t waves = grid * kWavesPerBlock;
+        const uint32_t fair = ((realtime ? (n + waves - 1u) / waves : n / (waves * 4u)) + 63u) & ~63u;
+        const uint32_t chunk = std::max(64u, realtime ? fair : std::min(ctx->pool_chunk, fair));
         // realtime: when every wave of the launch has a chunk of its own, the chunks are dealt by wave index
         const uint32_t static_bit = (realtime && (uint64_t)chunk * grid * kWavesPerBlock >= n) ? 0x80000000u : 0u;
         SceneView v = ctx->view;
@@ -544,8 +549,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const uint32_t tiles = (n + 63u) / 64u;
         const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
-        const uint32_t fair = (n / (grid * kWavesPerBlock * (realtime ? 1u : 4u)) + 63u) & ~63u; // as for the path pool
-        uint32_t chunk = std::max(64u, std::min(ctx->pool_chunk, fair));
+        const uint32_t waves = grid * kWavesPerBlock;
+        const uint32_t fair = ((realtime ? (n + waves - 1u) / waves : n / (waves * 4u)) + 63u) & ~63u; // as for the path pool
+        uint32_t chunk = std::max(64u, realtime ? fair : std::min(ctx->pool_chunk, fair));
         if (realtime && (uint64_t)chunk * grid * kWavesPerBlock >= n) chunk |= 0x80000000u; // chunks dealt by wave index
         HIP_TRY(ctx, send_pool_consts());
         // big trees (a million spheres: a node fetch is an L2 miss more often than not) turn to their leaves earlier: the
@@ -693,7 +699,7 @@ bool apply_tuning(pt_ctx *ctx, const pt_tuning &t) {
     case PT_PASS_PERSISTENT: // list scenes through the persistent queue form, offline passes included
         ctx->path_pool = false;
         break;
-    case PT_PASS_PATH_POOL:
+    case PT_PASS_PATH_POOL: ctx->pool_rt_min = 0; break; // realtime frames of any size through the pool too
     case PT_PASS_TREE_POOL: break; // what offline passes use anyway
     default: return false;
     }
