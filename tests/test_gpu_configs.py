@@ -359,7 +359,8 @@ def test_pool_on_tiny_and_ragged_passes(w, h, spp):
     assert int(st_a.segments) == int(st_b.segments)
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke"])
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "two_spheres", "two_perlin_spheres", "textured_sphere",
+                                  "simple_light"])
 def test_realtime_frames_of_a_list_scene_through_the_pool(name):
     """Realtime frames of a list scene run through the path pool from half a million pixels up (its waves evaluate the
     80 % pixel skip of 64 path ids at a time before they make camera samples, and take their chunks of ids by wave
