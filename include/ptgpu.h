@@ -183,8 +183,9 @@ typedef struct pt_tuning {
     uint32_t pool_chunk;           /* pool kernels: path ids a wave takes from the pass's counter at a time (64..2^20) */
     uint32_t pool_grid;            /* pool kernels: workgroups per resident slot (1..256) */
     uint32_t tree_refill, tree_inner, tree_shade; /* tree pool thresholds in lanes (1..64): refill at / stay on inner
-                                                     nodes while (default 16, trees of 32 768 nodes and more 24)
-                                                     / shade when this many lanes ... */
+                                                     nodes while (default 16, trees of 32 768 nodes and more 24,
+                                                     realtime frames 4) / shade when this many lanes (default 32,
+                                                     realtime frames 48) ... */
     uint32_t tree_trav_plus1;      /* ... or at most this many minus one (1..65) still traverse */
     uint32_t accel_form;           /* extend stage over the SAH tree: 1 = a ray per thread, 2 = refilled lane pool */
     uint32_t accel_refill, accel_inner, accel_grid; /* lane pool thresholds (1..64, 1..65) and workgroups per slot (1..8) */

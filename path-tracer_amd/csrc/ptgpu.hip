@@ -149,7 +149,8 @@ struct pt_ctx {
     uint32_t persist_factor = 1;
     bool tree_pool = true;        // offline passes of tree scenes as one k_tree_pool launch
     uint32_t tree_tuning[4] = {16, 16, 32, 4}; // refill at / inner min / shade min / traversing min
-    bool tree_inner_set = false;               // inner min came from pt_config (else big trees use 24)
+    bool tree_inner_set = false;               // inner min came from pt_config (else big trees use 24, realtime frames 4)
+    bool tree_shade_set = false;               // shade min came from pt_config (else realtime frames use 48)
     void *d_pool_consts = nullptr;
     std::deque<PoolConsts> h_pool_consts; // host copies of the passes in flight (cleared at every stream synchronisation of a render)
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
@@ -557,8 +558,13 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         // big trees (a million spheres: a node fetch is an L2 miss more often than not) turn to their leaves earlier: the
         // lanes left on inner nodes would each wait a full memory round trip per step (one million spheres +3 %; the
         // small trees lose 4 % with it)
-        const uint32_t inner_min = ctx->tree_inner_set ? ctx->tree_tuning[1] : (ctx->n_accel_nodes >= kAccelQuantFrom ? 24u : ctx->tree_tuning[1]);
-        const uint32_t tuning = ctx->tree_tuning[0] | (inner_min << 8) | (ctx->tree_tuning[2] << 16) | (ctx->tree_tuning[3] << 24);
+        // A realtime frame gives a wave some hundred paths in all, and its lanes thin out soon: the few that are still on
+        // inner nodes must keep stepping, and shading waits for a fuller batch (1080p frames: final scene 616 -> 668 per
+        // second, RTiOW 2 307 -> 2 528).
+        const uint32_t inner_min = ctx->tree_inner_set ? ctx->tree_tuning[1]
+                                   : realtime ? 4u : (ctx->n_accel_nodes >= kAccelQuantFrom ? 24u : ctx->tree_tuning[1]);
+        const uint32_t shade_min = ctx->tree_shade_set ? ctx->tree_tuning[2] : (realtime ? 48u : ctx->tree_tuning[2]);
+        const uint32_t tuning = ctx->tree_tuning[0] | (inner_min << 8) | (shade_min << 16) | (ctx->tree_tuning[3] << 24);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
@@ -709,7 +715,7 @@ bool apply_tuning(pt_ctx *ctx, const pt_tuning &t) {
     // a refill threshold above 64 would never be met: the kernel could not end
     if (t.tree_refill) { if (!in(t.tree_refill, 1, 64)) return false; ctx->tree_tuning[0] = t.tree_refill; }
     if (t.tree_inner) { if (!in(t.tree_inner, 1, 64)) return false; ctx->tree_tuning[1] = t.tree_inner; ctx->tree_inner_set = true; }
-    if (t.tree_shade) { if (!in(t.tree_shade, 1, 64)) return false; ctx->tree_tuning[2] = t.tree_shade; }
+    if (t.tree_shade) { if (!in(t.tree_shade, 1, 64)) return false; ctx->tree_tuning[2] = t.tree_shade; ctx->tree_shade_set = true; }
     if (t.tree_trav_plus1) { if (!in(t.tree_trav_plus1, 1, 65)) return false; ctx->tree_tuning[3] = t.tree_trav_plus1 - 1; }
     if (t.accel_form) {
         if (!in(t.accel_form, 1, 2)) return false;
