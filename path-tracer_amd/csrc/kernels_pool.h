@@ -17,6 +17,15 @@ struct PoolConsts {
     CameraDev cam;
     PassParams pp;
 };
+// Puts a pass's constants where the pool kernels read them. They arrive as kernel arguments, i.e. with the launch packet:
+// a copy from pageable host memory costs the host a staging copy and a wait of its own per pass, which a realtime frame
+// of a fifth of a millisecond notices.
+__global__ void k_set_pool_consts(PoolConsts value, PoolConsts *dst) {
+    constexpr uint32_t kWords = sizeof(PoolConsts) / sizeof(uint32_t);
+    static_assert(sizeof(PoolConsts) % sizeof(uint32_t) == 0, "copied word by word");
+    const uint32_t *src = (const uint32_t *)&value;
+    for (uint32_t k = threadIdx.x; k < kWords; k += blockDim.x) ((uint32_t *)dst)[k] = src[k];
+}
 struct PoolLds {
     LdsLeaf leaves[kLdsLeaves];
     // camera samples made 64 at a time by the whole wave and handed to lanes as they fall free

@@ -21,7 +21,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <mutex>
 #include <new>
 #include <cstddef>
@@ -152,7 +151,6 @@ struct pt_ctx {
     bool tree_inner_set = false;               // inner min came from pt_config (else big trees use 24, realtime frames 4)
     bool tree_shade_set = false;               // shade min came from pt_config (else realtime frames use 48)
     void *d_pool_consts = nullptr;
-    std::deque<PoolConsts> h_pool_consts; // host copies of the passes in flight (cleared at every stream synchronisation of a render)
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
     uint32_t pool_rt_min = 1u << 19; // realtime frames of list scenes: path ids from which the pool is used (below: the queue form)
@@ -468,8 +466,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
             if (hipError_t e = hipMalloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
-        ctx->h_pool_consts.emplace_back(PoolConsts{ctx->cam, pp}); // must outlive the asynchronous copy
-        return hipMemcpyAsync(ctx->d_pool_consts, &ctx->h_pool_consts.back(), sizeof(PoolConsts), hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp}, (PoolConsts *)ctx->d_pool_consts);
+        return hipGetLastError();
     };
     if (pool || tree || xpool) {
         // no ray generation launch: the pool kernels make their own camera samples
@@ -1120,7 +1118,6 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->h_pool_consts.clear();
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }
