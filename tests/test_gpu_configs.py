@@ -378,6 +378,15 @@ def test_realtime_frames_of_a_list_scene_through_the_pool(name):
             assert int(ctx.stats().last_pass_form) == form
             ctx.close()
         assert np.array_equal(images[ptgpu.PT_PASS_PATH_POOL], images[ptgpu.PT_PASS_PERSISTENT], equal_nan=True), (w, h)
+    # the rows of a group of two, frame by frame into one image, are the whole frames (the pool maps its path ids to the
+    # member's rows)
+    ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 20, pass_form=ptgpu.PT_PASS_PATH_POOL)
+    ctx.upload(scene)
+    for frame in range(4):
+        for phase in (0, 1):
+            ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=frame, rows=(2, phase))
+    assert np.array_equal(ctx.readback(), images[ptgpu.PT_PASS_PATH_POOL], equal_nan=True)
+    ctx.close()
     ref = np.zeros((h, w, 4), dtype=np.float32)
     counts = np.zeros((h, w), dtype=np.uint32)
     for frame in range(4):
