@@ -243,7 +243,7 @@ EXPORTS = [
     "pt_session_free", "pt_session_frame", "pt_scene_accel_info", "pt_scene_refit", "pt_scene_build_device",
     "pt_abi_version", "pt_intersect_static", "pt_asset_register_image", "pt_group_unique_id", "pt_group_join",
     "pt_group_join_local", "pt_group_rows", "pt_group_gather", "pt_group_gather_local", "pt_group_leave",
-    "pt_group_loopback", "pt_present_attach", "pt_present_slot", "pt_present_pinned", "pt_present_submit", "pt_present_wait", "pt_present_detach",
+    "pt_group_loopback", "pt_render_jobs", "pt_present_attach", "pt_present_slot", "pt_present_pinned", "pt_present_submit", "pt_present_wait", "pt_present_detach",
 ]
 
 _vp = C.c_void_p
@@ -264,6 +264,7 @@ _sig("pt_last_error", C.c_char_p, _vp)
 _sig("pt_scene_upload", C.c_int, _vp, C.POINTER(SceneDesc))
 _sig("pt_camera_set", C.c_int, _vp, C.POINTER(Camera))
 _sig("pt_render", C.c_int, _vp, C.POINTER(RenderArgs))
+_sig("pt_render_jobs", C.c_int, _vp, C.POINTER(RenderArgs), C.c_size_t)
 _sig("pt_accum_reset", C.c_int, _vp)
 _sig("pt_readback", C.c_int, _vp, C.POINTER(C.c_float), C.c_size_t)
 _sig("pt_image_device_ptr", _vp, _vp)
@@ -532,6 +533,17 @@ class Context:
         step, phase = rows if rows is not None else (1, 0)
         a = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp, max_depth, mode, frame, flags, step, phase)
         self._check(lib.pt_render(self._h, C.byref(a)), "pt_render")
+        self.width, self.height = width, height
+
+    def render_jobs(self, width, height, spp, max_depth, tiles, mode=PT_MODE_OFFLINE, frame=0, flags=0, rows=None, spp_of=None):
+        """A batch of tile jobs, one per rectangle (x0, y0, x1, y1) of `tiles` (pt_render_jobs). spp_of: optional list
+        of per-job sample counts (a batch that does not agree is run job by job)."""
+        step, phase = rows if rows is not None else (1, 0)
+        jobs = (RenderArgs * len(tiles))()
+        for k, (x0, y0, x1, y1) in enumerate(tiles):
+            jobs[k] = RenderArgs(C.sizeof(RenderArgs), width, height, x0, y0, x1, y1, spp_of[k] if spp_of else spp, max_depth, mode,
+                                 frame, flags, step, phase)
+        self._check(lib.pt_render_jobs(self._h, jobs, len(tiles)), "pt_render_jobs")
         self.width, self.height = width, height
 
     def refit(self, time0, time1):

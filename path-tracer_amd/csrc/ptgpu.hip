@@ -1122,6 +1122,46 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
     return PT_OK;
 }
 
+// A batch of tile jobs. The reference cuts the image into tiles because its workers are threads; here a tile is a pass of
+// its own (launches, a drain, a synchronisation), and a hundred of them cost a realtime frame thirty times its tracing
+// time. Paths are keyed by global pixel and sample, so the pixels do not depend on how the image is cut: a batch whose
+// jobs agree in everything but their rectangles, and whose rectangles tile their bounding box exactly, is traced as ONE
+// job over that box, bit-identical to the jobs run one by one. Any other batch runs job by job.
+int pt_render_jobs(pt_ctx *ctx, const pt_render_args *jobs, size_t n_jobs) {
+    if (!ctx || (!jobs && n_jobs)) return PT_ERR_INVALID_ARG;
+    if (n_jobs == 0) return PT_OK;
+    for (size_t k = 0; k < n_jobs; ++k)
+        if (jobs[k].struct_size != sizeof(pt_render_args)) return PT_ERR_INVALID_ARG;
+    bool merge = n_jobs > 1;
+    pt_render_args box = jobs[0];
+    uint64_t area = 0;
+    for (size_t k = 0; k < n_jobs && merge; ++k) {
+        const pt_render_args &j = jobs[k];
+        merge = j.width == box.width && j.height == box.height && j.spp == box.spp && j.max_depth == box.max_depth &&
+                j.mode == box.mode && j.frame == box.frame && j.flags == box.flags && j.row_step == box.row_step &&
+                j.row_phase == box.row_phase && j.x0 < j.x1 && j.y0 < j.y1;
+        if (!merge) break;
+        box.x0 = std::min(box.x0, j.x0);
+        box.y0 = std::min(box.y0, j.y0);
+        box.x1 = std::max(box.x1, j.x1);
+        box.y1 = std::max(box.y1, j.y1);
+        area += (uint64_t)(j.x1 - j.x0) * (j.y1 - j.y0);
+    }
+    // disjoint rectangles inside a box whose area they add up to cover it exactly
+    merge = merge && area == (uint64_t)(box.x1 - box.x0) * (box.y1 - box.y0) && n_jobs <= 4096;
+    for (size_t a = 0; a < n_jobs && merge; ++a)
+        for (size_t b = a + 1; b < n_jobs && merge; ++b)
+            merge = jobs[a].x1 <= jobs[b].x0 || jobs[b].x1 <= jobs[a].x0 || jobs[a].y1 <= jobs[b].y0 || jobs[b].y1 <= jobs[a].y0;
+    // (rows dealt between GPUs start at y0 + row_phase of each job: the jobs' rows are the box's rows only if every
+    // job starts on the box's row grid)
+    if (merge && box.row_step > 1)
+        for (size_t k = 0; k < n_jobs && merge; ++k) merge = (jobs[k].y0 - box.y0) % box.row_step == 0;
+    if (merge) return pt_render(ctx, &box);
+    for (size_t k = 0; k < n_jobs; ++k)
+        if (int rc = pt_render(ctx, &jobs[k]); rc != PT_OK) return rc;
+    return PT_OK;
+}
+
 int pt_accum_reset(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);

@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
     state.config = config;
     SceneOutput output;
     output.ctx = ctx;
-    // tile jobs as in src/lib.rs:345-394; each job is one pt_render call
+    // tile jobs as in src/lib.rs:345-394, dispatched as one batch per frame (src/lib.rs:396-399)
     auto tiles = make_tile_grid(nx, ny);
     output.remaining_tasks = (uint32_t)tiles.size();
     std::printf("Tracing... %zu tasks\n", tiles.size());
@@ -73,12 +73,13 @@ int main(int argc, char **argv) {
     auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; ++f) {
         state.frame = (uint32_t)f;
-        for (auto &t : tiles) {
-            TraceSceneBatchJob job(config.spp, {t[0], t[1]}, {t[2], t[3]}, {nx, ny}, &state, &output, config.realtime);
-            if ((rc = job.run()) != PT_OK) {
-                std::fprintf(stderr, "render failed: %d %s\n", rc, pt_last_error(ctx));
-                return 1;
-            }
+        std::vector<TraceSceneBatchJob> jobs;
+        for (auto &t : tiles)
+            jobs.emplace_back(config.spp, std::array<uint32_t, 2>{t[0], t[1]}, std::array<uint32_t, 2>{t[2], t[3]},
+                              std::array<uint32_t, 2>{nx, ny}, &state, &output, config.realtime);
+        if ((rc = dispatch_jobs(jobs)) != PT_OK) {
+            std::fprintf(stderr, "render failed: %d %s\n", rc, pt_last_error(ctx));
+            return 1;
         }
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -702,7 +702,7 @@ TraceSceneBatchJob::TraceSceneBatchJob(uint32_t num_samples, std::array<uint32_t
     : num_samples_(num_samples), start_xy_(start_xy), end_xy_(end_xy), image_size_(image_size), state_(state),
       output_(output), realtime_(realtime) {}
 
-int TraceSceneBatchJob::run() {
+pt_render_args TraceSceneBatchJob::render_args() const {
     pt_render_args a;
     std::memset(&a, 0, sizeof(a));
     a.struct_size = sizeof(a);
@@ -716,8 +716,25 @@ int TraceSceneBatchJob::run() {
     a.max_depth = (uint32_t)state_->config.max_depth;
     a.mode = realtime_ ? PT_MODE_REALTIME : PT_MODE_OFFLINE;
     a.frame = state_->frame;
+    return a;
+}
+int TraceSceneBatchJob::run() {
+    const pt_render_args a = render_args();
     int rc = pt_render(state_->ctx, &a);
     if (output_) output_->notify_task_completion();
+    return rc;
+}
+int dispatch_jobs(std::vector<TraceSceneBatchJob> &jobs) {
+    if (jobs.empty()) return PT_OK;
+    std::vector<pt_render_args> args;
+    args.reserve(jobs.size());
+    for (const TraceSceneBatchJob &j : jobs) {
+        if (j.context() != jobs[0].context()) return PT_ERR_INVALID_ARG; // one batch, one context
+        args.push_back(j.render_args());
+    }
+    const int rc = pt_render_jobs(jobs[0].context(), args.data(), args.size());
+    for (const TraceSceneBatchJob &j : jobs)
+        if (j.output()) j.output()->notify_task_completion();
     return rc;
 }
 void TraceSceneBatchJob::clear_buffer() { pt_accum_reset(state_->ctx); }

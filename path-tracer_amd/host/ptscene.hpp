@@ -226,6 +226,9 @@ class TraceSceneBatchJob {
                        std::array<uint32_t, 2> image_size, SceneState *state, SceneOutput *output, bool realtime);
     int run(); // JobTask::run -> trace(); returns a pt_status
     void clear_buffer();
+    pt_render_args render_args() const; // this job as the C ABI takes it
+    pt_ctx *context() const { return state_->ctx; }
+    SceneOutput *output() const { return output_; }
 
   private:
     uint32_t num_samples_;
@@ -234,6 +237,10 @@ class TraceSceneBatchJob {
     SceneOutput *output_;
     bool realtime_;
 };
+
+// Jobs::dispatch_jobs + wait_for_counter (src/lib.rs:396-399,476-478) for a batch of tile jobs bound to one context:
+// the batch goes to the library in one call, which traces a batch that tiles a rectangle as one pass (pt_render_jobs).
+int dispatch_jobs(std::vector<TraceSceneBatchJob> &jobs);
 
 // The body of the realtime main loop (src/lib.rs:406-478) without the window: per frame it advances the scene time,
 // applies the exposure / sky / emissive keys and the camera input, clears the accumulation when something moved,

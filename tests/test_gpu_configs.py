@@ -394,3 +394,64 @@ def test_realtime_frames_of_a_list_scene_through_the_pool(name):
     got = images[ptgpu.PT_PASS_PATH_POOL]
     assert (got[counts == 0][..., :3] == 0).all()
     assert np.isclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6, equal_nan=True).mean() >= 0.98
+
+
+def _tile_grid(w, h, n):
+    tw, th = (w + n - 1) // n, (h + n - 1) // n
+    return [(x, y, min(x + tw, w), min(y + th, h)) for y in range(0, h, th) for x in range(0, w, tw)]
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "random_scene"])
+def test_batch_of_tile_jobs(name):
+    """pt_render_jobs, the reference's dispatch of one job per tile (src/lib.rs:380-399): a batch that tiles a rectangle
+    is traced as one pass and gives, bit for bit, the image of the jobs run one by one; batches that cannot be merged
+    (a hole, overlapping tiles, unequal sample counts) are run job by job with the same result as pt_render calls."""
+    scene = ptgpu.Scene.named(name, 1.25)
+    w, h = 150, 120
+    ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 20)
+    ctx.upload(scene)
+    tiles = _tile_grid(w, h, 10)
+    assert len(tiles) == 100
+
+    def one_by_one(jobs, spp_of=None, mode=ptgpu.PT_MODE_OFFLINE, frames=1):
+        ctx.reset()
+        for f in range(frames):
+            for k, t in enumerate(jobs):
+                ctx.render(w, h, spp_of[k] if spp_of else 3, 12, tile=t, mode=mode, frame=f)
+        return ctx.readback(), int(ctx.stats().launches_resolve)
+
+    def batched(jobs, spp_of=None, mode=ptgpu.PT_MODE_OFFLINE, frames=1):
+        ctx.reset()
+        for f in range(frames):
+            ctx.render_jobs(w, h, 3, 12, jobs, mode=mode, frame=f, spp_of=spp_of)
+        return ctx.readback(), int(ctx.stats().launches_resolve)
+
+    ctx.stats_reset()
+    ref, n_ref = one_by_one(tiles)
+    ctx.stats_reset()
+    got, n_got = batched(tiles)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert n_ref == 100 and n_got == 1  # one pass for the whole grid
+    # realtime frames accumulate the same way
+    ref, _ = one_by_one(tiles, mode=ptgpu.PT_MODE_REALTIME, frames=3)
+    got, _ = batched(tiles, mode=ptgpu.PT_MODE_REALTIME, frames=3)
+    assert np.array_equal(got, ref, equal_nan=True)
+    # a sub-rectangle of the image, shuffled
+    sub = [t for t in tiles if 15 <= t[0] < 105 and 24 <= t[1] < 96][::-1]
+    ref, _ = one_by_one(sub)
+    ctx.stats_reset()
+    got, n_got = batched(sub)
+    assert np.array_equal(got, ref, equal_nan=True) and n_got == 1
+    # not mergeable: a hole; overlapping tiles (the later job overwrites); unequal sample counts
+    hole = tiles[:37] + tiles[38:]
+    overlap = tiles + [(10, 10, 40, 30)]
+    spp_of = [3 if k % 2 else 2 for k in range(len(tiles))]
+    for jobs, spps in ((hole, None), (overlap, None), (tiles, spp_of)):
+        ref, n_ref = one_by_one(jobs, spps)
+        ctx.stats_reset()
+        got, n_got = batched(jobs, spps)
+        assert np.array_equal(got, ref, equal_nan=True)
+        assert n_got == len(jobs)
+    with pytest.raises(ptgpu.PtError):
+        ctx.render_jobs(w, h, 3, 12, [(0, 0, w + 1, h)])
+    ctx.close()
