@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
         int32_t id;
         if constexpr (X) {
             unsigned long long unused_nodes = 0, unused_prims = 0;
-            extend_scan_walk<true, true, FUSE == 2, false>(sv, o, d, time, pkey, depth, 0.001, kF64Max, has, false, ht, id,
+            // FUSE 3 / 4 (exact mode only): as 1 / 2 for a stream without ENTER / EXIT ops, whose ray never changes frame
+            extend_scan_walk<true, FUSE <= 2, FUSE == 2 || FUSE == 4, false>(sv, o, d, time, pkey, depth, 0.001, kF64Max, has, false, ht, id,
                                                            unused_nodes, unused_prims);
         } else {
             extend_list<FUSE == 2>(sv, sv.ops, o, d, time, pkey, depth, 0.001, kF64Max, ht, id); // free lanes walk along

@@ -300,28 +300,34 @@ template <bool X> PT_DEV void unxform_hit(const DevXform &x, D3 &p, D3 &n) {
 // AABB::hit (src/math/aabb.rs:27-47). inv = 1/d per axis is hoisted out of the per-node loop: the reference
 // recomputes the same quotient at every node, so the values are identical.
 PT_DEV bool aabb_hit(const double *b, D3 o, D3 inv, double tmin, double tmax) {
+    // The reference returns false at the first axis whose interval is empty; the later axes cannot turn that into a hit,
+    // so all three are evaluated here without a branch (the same comparisons on the same values, NaN included).
+    bool ok;
     {
         double t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
-        if (inv.x < 0.0) { double t = t0; t0 = t1; t1 = t; }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) return false;
+        const bool neg = inv.x < 0.0;
+        const double lo = neg ? t1 : t0, hi = neg ? t0 : t1;
+        tmin = lo > tmin ? lo : tmin;
+        tmax = hi < tmax ? hi : tmax;
+        ok = !(tmax <= tmin);
     }
     {
         double t0 = (b[1] - o.y) * inv.y, t1 = (b[4] - o.y) * inv.y;
-        if (inv.y < 0.0) { double t = t0; t0 = t1; t1 = t; }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) return false;
+        const bool neg = inv.y < 0.0;
+        const double lo = neg ? t1 : t0, hi = neg ? t0 : t1;
+        tmin = lo > tmin ? lo : tmin;
+        tmax = hi < tmax ? hi : tmax;
+        ok = ok & !(tmax <= tmin);
     }
     {
         double t0 = (b[2] - o.z) * inv.z, t1 = (b[5] - o.z) * inv.z;
-        if (inv.z < 0.0) { double t = t0; t0 = t1; t1 = t; }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) return false;
+        const bool neg = inv.z < 0.0;
+        const double lo = neg ? t1 : t0, hi = neg ? t0 : t1;
+        tmin = lo > tmin ? lo : tmin;
+        tmax = hi < tmax ? hi : tmax;
+        ok = ok & !(tmax <= tmin);
     }
-    return true;
+    return ok;
 }
 
 // Sphere::hit / MovingSphere::hit root selection (src/sphere.rs:44-81, 137-175). which = 0 near root, 1 far root.

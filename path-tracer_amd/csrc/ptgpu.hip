@@ -531,8 +531,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         with_tex(ctx->tex, [&](auto T) {
             constexpr int kTex = decltype(T)::value;
             if (xpool) {
-                if (media) launch(k_path_pool<kTex, 2, true>);
-                else launch(k_path_pool<kTex, 1, true>);
+                const bool frames = ctx->view.has_frames != 0;
+                if (media) {
+                    if (frames) launch(k_path_pool<kTex, 2, true>);
+                    else launch(k_path_pool<kTex, 4, true>);
+                } else if (frames) launch(k_path_pool<kTex, 1, true>);
+                else launch(k_path_pool<kTex, 3, true>);
             } else if (media) {
                 if (realtime) launch(k_path_pool<kTex, 2, false, true>);
                 else launch(k_path_pool<kTex, 2>);
