@@ -313,11 +313,34 @@ def test_tree_pool_gives_the_same_image(name, param, rflags):
         assert int(st_a.segments) == int(st_b.segments), tuning
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke"])
+def _wrapped_subtree_scene(with_medium):
+    """A short stream WITH frames: a BVH of spheres under translate(rotate_y(...)) (ENTER / EXIT ops in the stream, as
+    around the sphere cluster of the final scene), on a lit stage; optionally a medium in a wrapped box."""
+    s = ptgpu.Scene(seed=77)
+    white = s.lambertian(s.texture_constant((0.73, 0.73, 0.73)))
+    green = s.lambertian(s.texture_constant((0.12, 0.45, 0.15)))
+    light = s.diffuse_light(s.texture_constant((9.0, 9.0, 9.0)))
+    rng = np.random.default_rng(5)
+    balls = [s.sphere(tuple(rng.uniform(0, 120, 3)), 12.0, white if k % 2 else s.dielectric(1.5)) for k in range(6)]
+    cluster = s.translate(s.rotate_y(s.bvh(balls, 0.0, 1.0), 15.0), (200.0, 150.0, 250.0))
+    nodes = [s.flip_normals(s.rect(150, 400, 150, 400, 554, 1, light)), s.rect(0, 555, 0, 555, 0, 1, white),
+             s.flip_normals(s.rect(0, 555, 0, 555, 555, 2, green)), cluster]
+    if with_medium:
+        box = s.translate(s.rotate_y(s.box((0, 0, 0), (120, 120, 120), white), -20.0), (60.0, 0.0, 120.0))
+        nodes.append(s.constant_medium(box, 0.01, s.texture_constant((1.0, 1.0, 1.0))))
+    s.set_root(s.bvh(nodes, 0.0, 1.0))
+    s.set_lights([s.rect(150, 400, 150, 400, 554, 1, white)])
+    s.camera = ptgpu.make_camera((278, 278, -760), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    assert s.flatten_info()["max_frame_depth"] == 1
+    return s
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "wrapped_subtree", "wrapped_subtree_medium"])
 def test_exact_mode_pool_gives_the_same_image(name):
     """Exact mode on short op streams: one pool launch per pass around the wave-uniform walk of the reference's own
-    tree against ray generation plus an extend and a shade launch per bounce. Bit-identical images."""
-    scene = ptgpu.Scene.named(name, 1.0)
+    tree against ray generation plus an extend and a shade launch per bounce. Bit-identical images. The recipes'
+    streams hold no ENTER / EXIT ops (the pool variants whose ray never changes frame); the two built scenes do."""
+    scene = ptgpu.Scene.named(name, 1.0) if not name.startswith("wrapped") else _wrapped_subtree_scene(name.endswith("medium"))
     w = h = 96
 
     def run(**tuning):
@@ -334,6 +357,10 @@ def test_exact_mode_pool_gives_the_same_image(name):
     assert int(st_b.last_pass_form) == ptgpu.PT_PASS_PATH_POOL
     assert np.array_equal(a, b, equal_nan=True)
     assert int(st_a.segments) == int(st_b.segments)
+    ref, _ = ob.render(scene.desc(), scene.camera, w, h, 12, 50, seed=0x5EED0001, threads=8)
+    finite = np.isfinite(b[..., :3]) & np.isfinite(ref[..., :3])
+    assert (np.isnan(b[..., :3]) == np.isnan(ref[..., :3])).mean() >= 0.995
+    assert (np.isclose(b[..., :3], ref[..., :3], rtol=1e-5, atol=1e-7) | ~finite).mean() >= 0.99
 
 
 @pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (7, 3, 5), (65, 2, 3), (256, 1, 257)])
