@@ -262,7 +262,29 @@ def main():
             # communicator set-up and staging buffers (seconds the first time) never land in the timed region,
             # also with --warmup 0
             ctx.render(W, H, 1, args.max_depth, frame=0, mode=mode, flags=rflags, rows=rows)
-            gather()
+            if args.gather == "capi":  # the first transfer through the library's communicator: same fallback as above
+                ok = torch.ones(1, dtype=torch.int32, device=image.device)
+                try:
+                    gather()
+                except pt.PtError as e:
+                    ok.zero_()
+                    gather_note.append(str(e))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not int(ok.item()):
+                    try:
+                        ctx.group_leave()
+                    except pt.PtError as e:
+                        gather_note.append(str(e))
+                    args.gather = "torch"
+                    gather_note.append("fell back to torch.distributed.gather")
+                    rows = tiles.rows_for(rank, world)
+                    pack = torch.zeros((tiles.max_rows(world, H), W, 4), dtype=torch.float32, device=image.device)
+                    if rank == 0:
+                        gather_list = [torch.zeros_like(pack) for _ in range(world)]
+                    ctx.render(W, H, 1, args.max_depth, frame=0, mode=mode, flags=rflags, rows=rows)
+                    gather()
+            else:
+                gather()
         for w in range(args.warmup):
             step(w)
         ctx.stats_reset()
