@@ -153,7 +153,7 @@ struct pt_ctx {
     void *d_pool_consts = nullptr;
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
-    uint32_t pool_rt_min = 1u << 19; // realtime frames of list scenes: path ids from which the pool is used (below: the queue form)
+    uint32_t pool_rt_min = 300000; // realtime frames of list scenes: path ids from which the pool is used (below: the queue form)
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
     uint32_t pool_chunk = 512;    // path ids a wave takes from the pass's counter at a time
@@ -451,9 +451,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // kernels). Realtime frames hold 0.4 M paths after the 80 % pixel skip; through the pool they measured 16 %
     // slower than through the persistent queue form below (four of five generated samples are skipped), which in
     // turn measured +53 % at 2^20 paths, +13 % at 2^22, -3 % at 2^24 against a launch per bounce.
-    // Realtime frames too (the waves evaluate the pixel skip before they make samples), from half a million pixels up:
-    // 1080p +46 %, 2160p +59 % against the queue form below; a 640 x 360 frame is all launch latency and runs 18 % faster
-    // through the queue form.
+    // Realtime frames too (the waves evaluate the pixel skip before they make samples), from 300 000 pixels up: 800 x 450
+    // +6 % (with media +20 %), 1080p +46 %, 2160p +59 % against the queue form below; a 640 x 360 frame is all launch
+    // latency and runs 18 % faster through the queue form.
     const bool pool = fused && ctx->path_pool && (!realtime || n >= ctx->pool_rt_min);
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
