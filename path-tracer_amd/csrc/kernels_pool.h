@@ -40,7 +40,12 @@ struct PoolLds {
 #ifndef PT_MEDIA_POOL_WAVES
 #define PT_MEDIA_POOL_WAVES 3 // the variant with media inside (FUSE == 2): at 4 waves per SIMD it holds 196 B of scratch per lane (smoke box: 1 570 -> 2 220 Mpaths/s)
 #endif
-constexpr int pool_waves(bool exact, int fuse) { return exact ? PT_EXACT_POOL_WAVES : (fuse == 2 ? PT_MEDIA_POOL_WAVES : PT_SHADE_WAVES); }
+#ifndef PT_EXACT_FLAT_POOL_WAVES
+#define PT_EXACT_FLAT_POOL_WAVES 4 // exact mode, stream without ENTER / EXIT ops (FUSE 3, 4): no frame ray to carry; Cornell box 3 -> 2 298, 4 -> 2 447, 5 -> 2 140 Mpaths/s; with a medium 3 and 4 tie
+#endif
+constexpr int pool_waves(bool exact, int fuse) {
+    return exact ? (fuse >= 3 ? PT_EXACT_FLAT_POOL_WAVES : PT_EXACT_POOL_WAVES) : (fuse == 2 ? PT_MEDIA_POOL_WAVES : PT_SHADE_WAVES);
+}
 // X: exact mode. The walk is the wave-uniform scan of the reference's own threaded tree (every box test, the
 // reference's order), the arithmetic is M<true>'s; sv.ops is then the full stream, not the fused list.
 // RT: a realtime frame (src/trace.rs:144-146: four of five pixels are skipped, by a draw keyed on seed, frame and pixel).

@@ -505,7 +505,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     if (pool || xpool) {
         const uint32_t tiles = (n + 63u) / 64u;
         const bool media = ctx->view.has_medium != 0;
-        const uint32_t resident = (uint32_t)ctx->n_cu * pool_waves(xpool, media ? 2 : 1) * ctx->pool_grid;
+        const bool frames = ctx->view.has_frames != 0;
+        // the kernel's FUSE parameter: 1 / 2 without / with media; exact mode on a stream without ENTER / EXIT ops: 3 / 4
+        const int fuse_id = (xpool && !frames) ? (media ? 4 : 3) : (media ? 2 : 1);
+        const uint32_t resident = (uint32_t)ctx->n_cu * pool_waves(xpool, fuse_id) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         // a small pass is cut into at least four chunks per wave so that the waves finish together
         // (a realtime frame's ids are mostly skipped pixels: one chunk per wave, or the chunk counter, one address for the
@@ -531,7 +534,6 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         with_tex(ctx->tex, [&](auto T) {
             constexpr int kTex = decltype(T)::value;
             if (xpool) {
-                const bool frames = ctx->view.has_frames != 0;
                 if (media) {
                     if (frames) launch(k_path_pool<kTex, 2, true>);
                     else launch(k_path_pool<kTex, 4, true>);
