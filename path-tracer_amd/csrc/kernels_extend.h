@@ -282,8 +282,7 @@ constexpr int kOpFirst = 1 << 25;  // fused lists: this XFORM op starts a chain 
 
 template <bool MEDIA> struct ListWalk {
     const SceneView &sv;
-    D3 o, d, inv;    // world ray
-    D3 fo, fd, finv; // the ray in the frame of the primitive that follows a run of XFORM ops
+    D3 o, d, inv; // world ray
     double dd, inv_dd, time, t_min, closest;
     uint64_t pkey;
     uint32_t depth;
@@ -304,22 +303,36 @@ template <bool MEDIA> struct ListWalk {
         closest = hit ? t : closest;
         best = hit ? (op.leaf | (sub << 28)) : best;
     }
-    // kword is wave-uniform, so these are scalar branches between straight-line blocks (no per-lane selects)
-    __device__ __forceinline__ void step(const DevOp &op, int kword) {
-        if ((kword & 0xff) == OP_XFORM) {
-            const DevXform x{op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], op.d[5]};
-            if (kword & kOpFirst) {
-                fo = o;
-                fd = d;
-                finv = inv;
-            }
-            xform_ray<false>(x, fo, fd);
-            if (x.s != 0.0) finv = d3(fast_rcp(fd.x), finv.y, fast_rcp(fd.z)); // a Y rotation leaves d.y alone
-        } else if (kword & kOpFramed) {
-            test(op, kword, fo, fd, finv);
-        } else {
-            test(op, kword, o, d, inv);
+    // One XFORM step on the frame ray (fo, fd, finv), which the caller seeds with the world ray
+    __device__ __forceinline__ void to_frame(const DevOp &op, D3 &fo, D3 &fd, D3 &finv) const {
+        const DevXform x{op.d[0], op.d[1], op.d[2], op.d[3], op.d[4], op.d[5]};
+        xform_ray<false>(x, fo, fd);
+        if (x.s != 0.0) finv = d3(fast_rcp(fd.x), finv.y, fast_rcp(fd.z)); // a Y rotation leaves d.y alone
+    }
+    // A run of XFORM ops and the primitive behind it, as one step: x holds the run's first op, y receives every record
+    // after it. On return x holds the record behind the primitive (loaded before the primitive's arithmetic was issued)
+    // and kx its kind word. The frame ray lives in this step and nowhere else: nothing of it is carried round the
+    // list loop, whose other steps test against the world ray.
+    __device__ __forceinline__ void framed(const DevOp *ops, int32_t &c, DevOp &x, int &kx, DevOp &y) {
+        const DevOp first = x; // the step's own copy: x is refilled at once with the record behind the primitive
+        y = load_op_uniform(ops + c + 1);
+        x = load_op_uniform(ops + c + 2); // an XFORM op is followed by a primitive and the sentinel at least
+        D3 fo = o, fd = d, finv = inv;
+        to_frame(first, fo, fd, finv);
+        int ky = __builtin_amdgcn_readfirstlane(y.kind);
+        c += 1;
+        if ((ky & 0xff) == OP_XFORM) { // a chain of more than one wrapper: its records are fetched as they are met
+            do {
+                to_frame(y, fo, fd, finv);
+                c += 1;
+                y = load_op_uniform(ops + c);
+                ky = __builtin_amdgcn_readfirstlane(y.kind);
+            } while ((ky & 0xff) == OP_XFORM);
+            x = load_op_uniform(ops + c + 1);
         }
+        test(y, ky, fo, fd, finv);
+        c += 1;
+        kx = __builtin_amdgcn_readfirstlane(x.kind);
     }
 };
 
@@ -333,22 +346,27 @@ __device__ __forceinline__ void extend_list(const SceneView &sv, const DevOp *op
                                             int32_t &best) {
     const D3 inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
     const double dd = M<false>::dot(d, d); // unchanged by the rigid XFORM steps
-    ListWalk<MEDIA> w{sv, o, d, inv, o, d, inv, dd, fast_rcp(dd), time, t_min, t_max, pkey, depth, -1};
+    ListWalk<MEDIA> w{sv, o, d, inv, dd, fast_rcp(dd), time, t_min, t_max, pkey, depth, -1};
     // The list ends with a sentinel EXIT op (a fused list holds no other), and the loop runs on the KIND of the
     // record it holds. Scalar loads return out of order, so the compiler can only ever wait for all of them: with
     // the loop test reading the current record, that wait falls before the loop and at the end of each step, after
     // the step's arithmetic has been issued, and never right behind the prefetch of the next record. Two records
-    // alternate (a, b) so that no record is ever copied.
-    DevOp a = load_op_uniform(ops);
-    int ka = __builtin_amdgcn_readfirstlane(a.kind);
-    for (int32_t c = 0;; c += 2) {
+    // alternate (a, b) so that no record is ever copied; a framed step consumes both and leaves the current record
+    // where it was.
+    DevOp a = load_op_uniform(ops), b;
+    int ka = __builtin_amdgcn_readfirstlane(a.kind), kb;
+    for (int32_t c = 0;;) {
+        while ((ka & 0xff) == OP_XFORM) w.framed(ops, c, a, ka, b);
         if ((ka & 0xff) == OP_EXIT) break;
-        const DevOp b = load_op_uniform(ops + c + 1);
-        w.step(a, ka);
-        const int kb = __builtin_amdgcn_readfirstlane(b.kind);
+        b = load_op_uniform(ops + c + 1);
+        w.test(a, ka, o, d, inv);
+        c += 1;
+        kb = __builtin_amdgcn_readfirstlane(b.kind);
+        while ((kb & 0xff) == OP_XFORM) w.framed(ops, c, b, kb, a);
         if ((kb & 0xff) == OP_EXIT) break;
-        a = load_op_uniform(ops + c + 2);
-        w.step(b, kb);
+        a = load_op_uniform(ops + c + 1);
+        w.test(b, kb, o, d, inv);
+        c += 1;
         ka = __builtin_amdgcn_readfirstlane(a.kind);
     }
     closest = w.closest;
