@@ -316,16 +316,24 @@ int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double 
                         uint64_t medium_seed, int repeats, double *mean_ms_out);
 
 /* No counterpart in the reference (the crate never touches a device). The variant of pt_intersect for callers that
- * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
- * d_rays (n pt_ray) and d_hits (n pt_hit) are DEVICE memory of the context's GPU, owned by the caller; the ray queue,
- * the hit records and the fill count the extend kernels work on live in a fixed array inside the library's device
- * image (about 6.8 MiB per GPU, held from the library's load to the end of the process), so the call performs no
- * hipMalloc / hipFree. At most PT_INTERSECT_STATIC_MAX_RAYS rays per call (PT_ERR_TOO_LARGE beyond that). Same hits
- * as pt_intersect, bit for bit. Synchronous. All contexts of one GPU share that GPU's array: calls that overlap in
- * time on one GPU (from several contexts or threads) race; calls on different GPUs do not. */
+ * cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc, processes in which another
+ * thread is capturing a HIP graph (an allocation would break that capture). d_rays (n pt_ray) and d_hits (n pt_hit)
+ * are DEVICE memory of the context's GPU, owned by the caller; the ray queue, the hit records and the fill count the
+ * extend kernels work on live in a fixed array inside the library's device image (about 6.8 MiB per GPU, held from
+ * the library's load to the end of the process), so the call performs no hipMalloc / hipFree
+ * (pt_device_alloc_count() does not move). It is NOT itself capturable into a caller's graph: it launches on the
+ * context's own stream, queries the two pointers and synchronises that stream before it returns. At most
+ * PT_INTERSECT_STATIC_MAX_RAYS rays per call (PT_ERR_TOO_LARGE beyond that). Same hits as pt_intersect, bit for bit.
+ * All contexts of one GPU share that GPU's array: calls that overlap in time on one GPU (from several contexts or
+ * threads) race; calls on different GPUs do not. */
 #define PT_INTERSECT_STATIC_MAX_RAYS 65536
 int pt_intersect_static(pt_ctx *ctx, const pt_ray *d_rays, size_t n, double t_min, double t_max,
                         uint64_t medium_seed, pt_hit *d_hits);
+
+/* Diagnostic, no counterpart in the reference: the number of device and page-locked host allocations (hipMalloc,
+ * hipHostMalloc) this library has made in the process so far. A caller that must not allocate brackets its calls
+ * with it (tests/test_zz_no_alloc.py does, around pt_intersect_static). */
+uint64_t pt_device_alloc_count(void);
 
 /* ------------------------------------------------------------------------ */
 /* Several GPUs: one context per GPU, one image                              */
@@ -349,6 +357,13 @@ int pt_group_unique_id(uint8_t *id_out, size_t n_bytes);                   /* n_
 int pt_group_join(pt_ctx *ctx, const uint8_t *id, size_t n_bytes, int rank, int world);
 int pt_group_join_local(pt_ctx *const *ctxs, int n);                       /* ctxs[k] becomes member k of n */
 int pt_group_rows(pt_ctx *ctx, uint32_t *row_step, uint32_t *row_phase);   /* this member's share: world, rank */
+/* The split as numbers, host only (no context, no GPU): for an image of `height` rows gathered to `root`, member
+ * `rank` of `world` traces *rows rows (rank, rank + world, ...), and in the root's staging buffer they start
+ * *staged_before rows in (the other members' rows lie one member behind the other in rank order; the root's own rows
+ * are never staged). pt_group_staged_row: the staging-buffer row that holds image row y, -1 for a row of the root's
+ * own or bad arguments. The gather's kernels run the same arithmetic (csrc/group_rows.h). */
+int pt_group_layout(uint32_t height, int world, int root, int rank, uint32_t *rows, uint64_t *staged_before);
+int64_t pt_group_staged_row(uint32_t height, int world, int root, uint32_t y);
 /* Collective over the group: every member calls it (or the one process calls pt_group_gather_local) after rendering
  * its rows of the same width x height image. Synchronous; on return the root's image holds every row. */
 int pt_group_gather(pt_ctx *ctx, int root);

@@ -244,6 +244,7 @@ EXPORTS = [
     "pt_abi_version", "pt_intersect_static", "pt_asset_register_image", "pt_group_unique_id", "pt_group_join",
     "pt_group_join_local", "pt_group_rows", "pt_group_gather", "pt_group_gather_local", "pt_group_leave",
     "pt_group_loopback", "pt_render_jobs", "pt_present_attach", "pt_present_slot", "pt_present_pinned", "pt_present_submit", "pt_present_wait", "pt_present_detach",
+    "pt_device_alloc_count", "pt_group_layout", "pt_group_staged_row",
 ]
 
 _vp = C.c_void_p
@@ -315,6 +316,9 @@ _sig("pt_group_unique_id", C.c_int, C.POINTER(C.c_uint8), C.c_size_t)
 _sig("pt_group_join", C.c_int, _vp, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int)
 _sig("pt_group_join_local", C.c_int, C.POINTER(_vp), C.c_int)
 _sig("pt_group_rows", C.c_int, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+_sig("pt_group_layout", C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64))
+_sig("pt_group_staged_row", C.c_int64, C.c_uint32, C.c_int, C.c_int, C.c_uint32)
+_sig("pt_device_alloc_count", C.c_uint64)
 _sig("pt_group_gather", C.c_int, _vp, C.c_int)
 _sig("pt_group_gather_local", C.c_int, C.POINTER(_vp), C.c_int, C.c_int)
 _sig("pt_group_leave", C.c_int, _vp)
@@ -677,6 +681,20 @@ def group_unique_id() -> bytes:
     if rc != PT_OK:
         raise PtError(rc, "pt_group_unique_id")
     return bytes(buf)
+
+
+def group_layout(height, world, root, rank):
+    """(rows member `rank` traces, rows before them in the root's staging buffer): pt_group_layout."""
+    rows, before = C.c_uint32(), C.c_uint64()
+    rc = lib.pt_group_layout(height, world, root, rank, C.byref(rows), C.byref(before))
+    if rc != PT_OK:
+        raise PtError(rc, "pt_group_layout")
+    return rows.value, before.value
+
+
+def device_alloc_count() -> int:
+    """Device / page-locked allocations the library has made in this process so far (pt_device_alloc_count)."""
+    return int(lib.pt_device_alloc_count())
 
 
 def group_join_local(contexts):

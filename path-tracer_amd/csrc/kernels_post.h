@@ -167,11 +167,10 @@ __global__ __launch_bounds__(kBlock) void k_store_hits(Queue q, uint32_t n, Scen
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pack_rows(const float4 *image, uint32_t width, uint32_t height, uint32_t step,
                                                       uint32_t phase, float4 *packed) {
-    const uint32_t rows = phase < height ? (height - phase + step - 1) / step : 0u;
-    const uint64_t n = (uint64_t)rows * width;
+    const uint64_t n = (uint64_t)group_rows_of(height, step, phase) * width;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint32_t k = (uint32_t)(i / width), x = (uint32_t)(i % width);
-        packed[i] = image[(uint64_t)(phase + k * step) * width + x];
+        packed[i] = image[(uint64_t)group_image_row(step, phase, k) * width + x];
     }
 }
 // Every member's packed rows except `skip`'s own (they are in the image already) lie one behind the other in
@@ -181,12 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_rows(float4 *image, uint32_t 
     const uint64_t n = (uint64_t)height * width;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i % width);
-        const uint32_t r = y % step;
-        if (r == skip) continue;
-        // rows held by the members that come before r in the buffer: member q holds ceil((height - q) / step) rows
-        uint64_t before = 0;
-        for (uint32_t q = 0; q < r; ++q)
-            if (q != skip && q < height) before += (height - q + step - 1) / step;
-        image[i] = packed[(before + y / step) * width + x];
+        if (y % step == skip) continue;
+        image[i] = packed[group_staged_row(height, step, skip, y) * width + x];
     }
 }

@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@
 
 #include "accel.h"
 #include "flatten.h"
+#include "group_rows.h"
 #include "pool_list.h"
 #include "pt_device.h"
 
@@ -61,6 +63,17 @@ constexpr size_t kStaticHitIdOffset = kStaticHitTOffset + (size_t)kStaticMaxRays
 constexpr size_t kStaticCountsOffset = kStaticHitIdOffset + (size_t)kStaticMaxRays * sizeof(int32_t);
 constexpr size_t kStaticScratchBytes = kStaticCountsOffset + 256;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+// Every allocation the library makes goes through these two, so that pt_device_alloc_count can say whether a call allocated.
+static std::atomic<uint64_t> g_alloc_count{0};
+template <typename T> static hipError_t counted_malloc(T **p, size_t bytes) {
+    g_alloc_count.fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc((void **)p, bytes);
+}
+static hipError_t counted_host_malloc(void **p, size_t bytes, unsigned int flags) {
+    g_alloc_count.fetch_add(1, std::memory_order_relaxed);
+    return hipHostMalloc(p, bytes, flags);
+}
 
 namespace {
 constexpr int kMaxDevices = 64;
@@ -226,7 +239,7 @@ template <typename T> int upload(pt_ctx *ctx, void **dst, const T *src, size_t c
         *dst = nullptr;
     }
     if (count == 0) return PT_OK;
-    HIP_TRY(ctx, hipMalloc(dst, count * sizeof(T)));
+    HIP_TRY(ctx, counted_malloc(dst, count * sizeof(T)));
     HIP_TRY(ctx, hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -255,7 +268,7 @@ int alloc_path_state(pt_ctx *ctx) {
     const size_t per_path = 2 * 96 + 3 * 8 + 8 + 4;
     const size_t n_arrays = 2 + 3 + 2;
     const size_t bytes = n * per_path + n_arrays * 256; // every array starts on a 256-byte boundary
-    HIP_TRY(ctx, hipMalloc(&ctx->d_pool, bytes));
+    HIP_TRY(ctx, counted_malloc(&ctx->d_pool, bytes));
     char *p = (char *)ctx->d_pool;
     auto take = [&](size_t sz) {
         char *r = p;
@@ -269,9 +282,9 @@ int alloc_path_state(pt_ctx *ctx) {
     for (int k = 0; k < 3; ++k) ctx->d_l[k] = (double *)take(n * 8);
     ctx->d_hit_t = (double *)take(n * 8);
     ctx->d_hit_id = (int32_t *)take(n * 4);
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)kMaxDepthSlots * kShards * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_stats, 2 * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_trav, sizeof(TraversalCounters)));
+    HIP_TRY(ctx, counted_malloc((void **)&ctx->d_counts, (size_t)kMaxDepthSlots * kShards * sizeof(uint32_t)));
+    HIP_TRY(ctx, counted_malloc((void **)&ctx->d_stats, 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, counted_malloc((void **)&ctx->d_trav, sizeof(TraversalCounters)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_trav, 0, sizeof(TraversalCounters), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -285,7 +298,7 @@ int ensure_image(pt_ctx *ctx, uint32_t w, uint32_t h) {
     } else if (!ctx->d_image_owned || w != ctx->width || h != ctx->height) {
         if (ctx->d_image_owned) (void)hipFree(ctx->d_image_owned);
         ctx->d_image_owned = nullptr;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_image_owned, (size_t)w * h * 4 * sizeof(float)));
+        HIP_TRY(ctx, counted_malloc((void **)&ctx->d_image_owned, (size_t)w * h * 4 * sizeof(float)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_image_owned, 0, (size_t)w * h * 4 * sizeof(float), ctx->stream));
         ctx->d_image = ctx->d_image_owned;
         ctx->width = w;
@@ -294,7 +307,7 @@ int ensure_image(pt_ctx *ctx, uint32_t w, uint32_t h) {
         ctx->d_frames = nullptr;
     }
     if (!ctx->d_frames) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames, (size_t)w * h * sizeof(uint32_t)));
+        HIP_TRY(ctx, counted_malloc((void **)&ctx->d_frames, (size_t)w * h * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_frames, 0, (size_t)w * h * sizeof(uint32_t), ctx->stream));
     }
     return PT_OK;
@@ -307,7 +320,7 @@ int ensure_acc(pt_ctx *ctx, size_t pixels) {
         ctx->d_acc[k] = nullptr;
     }
     ctx->acc_capacity = 0;
-    for (int k = 0; k < 3; ++k) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_acc[k], pixels * sizeof(double)));
+    for (int k = 0; k < 3; ++k) HIP_TRY(ctx, counted_malloc((void **)&ctx->d_acc[k], pixels * sizeof(double)));
     ctx->acc_capacity = pixels;
     return PT_OK;
 }
@@ -317,7 +330,7 @@ int ensure_stage(pt_ctx *ctx, int k, size_t bytes) {
     if (ctx->d_stage[k]) (void)hipFree(ctx->d_stage[k]);
     ctx->d_stage[k] = nullptr;
     ctx->stage_bytes[k] = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_stage[k], bytes));
+    HIP_TRY(ctx, counted_malloc(&ctx->d_stage[k], bytes));
     ctx->stage_bytes[k] = bytes;
     return PT_OK;
 }
@@ -465,7 +478,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
-            if (hipError_t e = hipMalloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
+            if (hipError_t e = counted_malloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
         hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp}, (PoolConsts *)ctx->d_pool_consts);
         return hipGetLastError();
     };
@@ -836,6 +849,8 @@ void pt_destroy(pt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+
+uint64_t pt_device_alloc_count(void) { return g_alloc_count.load(std::memory_order_relaxed); }
 
 const char *pt_last_error(pt_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 
@@ -1342,7 +1357,7 @@ int pt_present_attach(pt_ctx *ctx, void *host_staging, size_t slot_bytes, uint32
     if (!host_staging) {
         // the library's own ring: page-locked host memory the copy engines write at the full rate of the link
         void *ring = nullptr;
-        HIP_TRY(ctx, hipHostMalloc(&ring, slot_bytes * n_slots, hipHostMallocDefault));
+        HIP_TRY(ctx, counted_host_malloc(&ring, slot_bytes * n_slots, hipHostMallocDefault));
         host_staging = ring;
         ctx->present_owned = true;
     } else {
@@ -1404,7 +1419,7 @@ int pt_present_submit(pt_ctx *ctx, uint32_t slot, int kind, float exposure) {
         if (ctx->d_present[slot]) (void)hipFree(ctx->d_present[slot]);
         ctx->d_present[slot] = nullptr;
         ctx->present_bytes[slot] = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_present[slot], need));
+        HIP_TRY(ctx, counted_malloc(&ctx->d_present[slot], need));
         ctx->present_bytes[slot] = need;
     }
     if (kind == PT_PRESENT_RAW) {
@@ -1472,7 +1487,7 @@ static int quantise_nodes(pt_ctx *ctx) {
         g.gmin[a] = lo;
         g.cell[a] = hi > lo ? (hi - lo) / 65535.0 * (1.0 + 1e-12) : 1.0;
     }
-    HIP_TRY(ctx, hipMalloc(&ctx->d_accel_nodes_q, (size_t)n * sizeof(AccelNodeQ)));
+    HIP_TRY(ctx, counted_malloc(&ctx->d_accel_nodes_q, (size_t)n * sizeof(AccelNodeQ)));
     hipLaunchKernelGGL(k_accel_quantise, dim3(grid_for(ctx, (uint32_t)n)), dim3(kBlock), 0, ctx->stream,
                        (const AccelNode *)ctx->d_accel_nodes, (AccelNodeQ *)ctx->d_accel_nodes_q, n, g);
     HIP_TRY(ctx, hipGetLastError());
@@ -1542,22 +1557,22 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
         }
     } h;
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(ctx, hipMalloc(&h.keys[k], (size_t)n * sizeof(uint64_t)));
-        HIP_TRY(ctx, hipMalloc(&h.vals[k], (size_t)n * sizeof(uint32_t)));
+        HIP_TRY(ctx, counted_malloc(&h.keys[k], (size_t)n * sizeof(uint64_t)));
+        HIP_TRY(ctx, counted_malloc(&h.vals[k], (size_t)n * sizeof(uint32_t)));
     }
-    HIP_TRY(ctx, hipMalloc(&h.prims, (size_t)n * sizeof(DevOp)));
+    HIP_TRY(ctx, counted_malloc(&h.prims, (size_t)n * sizeof(DevOp)));
     // at most n - 1 nodes (every leaf a single primitive)
-    HIP_TRY(ctx, hipMalloc(&h.nodes, (size_t)n * sizeof(AccelNode)));
-    HIP_TRY(ctx, hipMalloc(&h.parent, (size_t)n * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc(&h.ranges, (size_t)n * sizeof(BuildRange)));
-    HIP_TRY(ctx, hipMalloc(&h.counter, sizeof(int32_t)));
+    HIP_TRY(ctx, counted_malloc(&h.nodes, (size_t)n * sizeof(AccelNode)));
+    HIP_TRY(ctx, counted_malloc(&h.parent, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, counted_malloc(&h.ranges, (size_t)n * sizeof(BuildRange)));
+    HIP_TRY(ctx, counted_malloc(&h.counter, sizeof(int32_t)));
     hipLaunchKernelGGL(k_accel_prim_codes, dim3(grid_for(ctx, (uint32_t)n)), dim3(kBlock), 0, ctx->stream,
                        (const DevOp *)ctx->d_accel_prims, ctx->view, n, time0, time1, D3{lo[0], lo[1], lo[2]},
                        D3{scale[0], scale[1], scale[2]}, (uint64_t *)h.keys[0], (uint32_t *)h.vals[0]);
     size_t temp_bytes = 0;
     HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint64_t *)h.keys[0], (uint64_t *)h.keys[1],
                                                     (const uint32_t *)h.vals[0], (uint32_t *)h.vals[1], n, 0, 63, ctx->stream));
-    HIP_TRY(ctx, hipMalloc(&h.temp, std::max<size_t>(temp_bytes, 16)));
+    HIP_TRY(ctx, counted_malloc(&h.temp, std::max<size_t>(temp_bytes, 16)));
     HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(h.temp, temp_bytes, (const uint64_t *)h.keys[0], (uint64_t *)h.keys[1],
                                                     (const uint32_t *)h.vals[0], (uint32_t *)h.vals[1], n, 0, 63, ctx->stream));
     hipLaunchKernelGGL(k_accel_gather_prims, dim3(grid_for(ctx, (uint64_t)n * 4)), dim3(kBlock), 0, ctx->stream,
@@ -1651,9 +1666,7 @@ int pt_stats_reset(pt_ctx *ctx) {
         }                                                                                                         \
     } while (0)
 
-static uint32_t rows_of_member(uint32_t height, uint32_t world, uint32_t rank) {
-    return rank < height ? (height - rank + world - 1) / world : 0u;
-}
+static uint32_t rows_of_member(uint32_t height, uint32_t world, uint32_t rank) { return group_rows_of(height, world, rank); }
 
 // The gather for the members of the group that live in this process (all of them, or one).
 static int group_gather(pt_ctx *const *m, int n_local, int root) {
@@ -1696,12 +1709,11 @@ static int group_gather(pt_ctx *const *m, int n_local, int root) {
     for (int k = 0; k < n_local; ++k) {
         pt_ctx *c = m[k];
         if (c->group_rank == root) {
-            size_t offset = 0;
             for (int r = 0; r < world; ++r) {
                 if (r == root) continue;
                 const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)r) * w * 4;
+                const size_t offset = (size_t)group_rows_before(h, (uint32_t)world, (uint32_t)root, (uint32_t)r) * w * 4;
                 if (count) NCCL_TRY_IN_GROUP(c, nccl->Recv((float *)c->d_stage[0] + offset, count, ncclFloat, r, c->comm, c->stream));
-                offset += count;
             }
         } else {
             const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)c->group_rank) * w * 4;
@@ -1770,6 +1782,18 @@ int pt_group_join_local(pt_ctx *const *ctxs, int n) {
         ctxs[k]->group_world = n;
     }
     return PT_OK;
+}
+
+int pt_group_layout(uint32_t height, int world, int root, int rank, uint32_t *rows, uint64_t *staged_before) {
+    if (world < 1 || root < 0 || root >= world || rank < 0 || rank >= world || !rows || !staged_before) return PT_ERR_INVALID_ARG;
+    *rows = group_rows_of(height, (uint32_t)world, (uint32_t)rank);
+    *staged_before = group_rows_before(height, (uint32_t)world, (uint32_t)root, (uint32_t)rank);
+    return PT_OK;
+}
+
+int64_t pt_group_staged_row(uint32_t height, int world, int root, uint32_t y) {
+    if (world < 1 || root < 0 || root >= world || y >= height || (int)(y % (uint32_t)world) == root) return -1;
+    return (int64_t)group_staged_row(height, (uint32_t)world, (uint32_t)root, y);
 }
 
 int pt_group_rows(pt_ctx *ctx, uint32_t *row_step, uint32_t *row_phase) {

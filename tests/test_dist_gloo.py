@@ -4,6 +4,7 @@ restricted to the rank's tile rectangles, so the assembled image must equal a si
 (the RNG is keyed by global pixel and sample, never by rank)."""
 import importlib
 import os
+from ctypes import c_uint32 as C_uint32, c_uint64 as C_uint64
 import socket
 import sys
 
@@ -107,15 +108,53 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     stops at the device check, after the world size has been checked against --gpus."""
     import subprocess
 
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
-    if torch.cuda.is_available():
+    if torch.cuda.is_available():  # before anything is started: with a GPU this would be a real two-rank benchmark
         pytest.skip("a GPU is present: covered by the rehearsal test")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    small = ["--width", "64", "--height", "64", "--spp", "1", "--paths-in-flight", str(1 << 16), "--no-exact", "--no-extend",
+             "--no-cpu-baseline", "--no-workloads"]
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"] + small,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
     assert proc.returncode != 0
     assert proc.stdout.count("bench.py needs an MI355X") >= 2, proc.stdout[-2000:]
     # a launcher that starts the wrong number of ranks is refused
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, stdout=subprocess.PIPE,
                           stderr=subprocess.STDOUT, text=True, env=env2, timeout=300)
     assert proc.returncode != 0 and "WORLD_SIZE=4" in proc.stdout
+
+
+@pytest.mark.parametrize("world", range(2, 9))
+def test_gather_layout_covers_every_row_once(world):
+    """The row arithmetic the gather's kernels run (csrc/group_rows.h through pt_group_layout / pt_group_staged_row),
+    replayed on the host: every member packs its rows, the root's staging buffer is their concatenation at the offsets
+    the root posts its receives at, and the scatter must find every image row exactly where its owner put it. Heights
+    the world size does not divide, and heights below it, included."""
+    import ptgpu
+
+    for height in (1, 2, 3, 5, 7, 8, 9, 16, 31, 64, 100, 1080):
+        for root in sorted({0, world - 1, world // 2}):
+            rows_of, before = zip(*[ptgpu.group_layout(height, world, root, r) for r in range(world)])
+            assert sum(rows_of) == height
+            assert [rows_of[r] for r in range(world)] == [len(range(r, height, world)) for r in range(world)]
+            # the root's receive offsets: members in rank order, the root itself left out, nothing overlapping
+            expect = 0
+            for r in range(world):
+                assert before[r] == expect
+                if r != root:
+                    expect += rows_of[r]
+            staged = np.full(expect, -1, dtype=np.int64)  # image row held by each staging-buffer row
+            for r in range(world):
+                if r == root:
+                    continue
+                packed = np.arange(r, height, world)  # k_pack_rows: row k of the buffer = image row rank + k * world
+                staged[before[r]:before[r] + rows_of[r]] = packed
+            assert (staged >= 0).all()
+            for y in range(height):  # k_unpack_rows
+                idx = ptgpu.lib.pt_group_staged_row(height, world, root, y)
+                if y % world == root:
+                    assert idx == -1
+                else:
+                    assert 0 <= idx < expect and staged[idx] == y
+    rows, before = C_uint32(), C_uint64()
+    assert ptgpu.lib.pt_group_layout(8, world, world, 0, rows, before) == ptgpu.PT_ERR_INVALID_ARG  # root outside the group

@@ -41,7 +41,11 @@ def test_static_entry_point_matches_pt_intersect(mode, name, gpu_ctx, gpu_ctx_ex
         d_rays = _on_device(torch, rays)
         d_hits = torch.full((n * ptgpu.HIT_DTYPE.itemsize,), 0xA5, dtype=torch.uint8, device="cuda:0")
         torch.cuda.synchronize()
+        # the property the entry point exists for: the library allocates nothing, and the device's free memory does not move
+        allocs, free_before = ptgpu.device_alloc_count(), torch.cuda.mem_get_info(0)[0]
         ctx.intersect_static(d_rays.data_ptr(), n, d_hits.data_ptr(), medium_seed=7)
+        assert ptgpu.device_alloc_count() == allocs
+        assert torch.cuda.mem_get_info(0)[0] == free_before
         got = d_hits.cpu().numpy().view(ptgpu.HIT_DTYPE)
         assert got.shape == want.shape
         assert (got["prim"] == want["prim"]).all() and (got["material"] == want["material"]).all()
@@ -67,7 +71,9 @@ def test_static_entry_point_limits(gpu_ctx):
     with pytest.raises(ptgpu.PtError) as e:  # one ray over the maximum: refused with a clear message, nothing runs
         gpu_ctx.intersect_static(d_rays.data_ptr(), n + 1, d_hits.data_ptr())
     assert e.value.code == ptgpu.PT_ERR_TOO_LARGE and "PT_INTERSECT_STATIC_MAX_RAYS" in str(e.value)
+    allocs = ptgpu.device_alloc_count()
     gpu_ctx.intersect_static(d_rays.data_ptr(), n, d_hits.data_ptr())  # the maximum itself fits
+    assert ptgpu.device_alloc_count() == allocs > 0  # ... without an allocation (the counter saw pt_create's)
     got = d_hits.cpu().numpy().view(ptgpu.HIT_DTYPE)[:n]
     want = gpu_ctx.intersect(rays[:n])
     assert (got["prim"] == want["prim"]).all() and (got["t"] == want["t"]).all()
