@@ -46,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode leg")
     ap.add_argument("--no-extend", action="store_true", help="skip the extend-stage leg")
+    ap.add_argument("--cfg-flags", type=int, default=0, help="extra PT_CFG_* bits for the timed context (8 = PT_CFG_FAT_RECORDS, A/B runs)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the legs over the other configurations (config.workloads)")
     ap.add_argument("--extend-cloud", type=int, default=1000000,
                     help="spheres of the second extend scene (0 skips it; its host build and oracle pass take ~1 min)")
@@ -301,7 +302,7 @@ def main():
             elapsed = float(t.item())
         return elapsed, ctx.stats(), image, ctx
 
-    elapsed, st, image, ctx = timed_leg(pt.PT_CFG_PROFILE_STAGES)
+    elapsed, st, image, ctx = timed_leg(pt.PT_CFG_PROFILE_STAGES | args.cfg_flags)
     value = paths_per_step * args.steps / elapsed / 1e6
     nan_frac = float(torch.isnan(image[..., :3]).any(dim=-1).float().mean().item()) if rank == 0 else 0.0
     ctx.close()

@@ -211,6 +211,9 @@ typedef struct pt_config {
                            and roots by refined hardware reciprocals, a*b+c fused, and sin / cos of 2 pi r from a
                            quadrant reduction and polynomials (a few ulp per operation) */
 
+#define PT_CFG_FAT_RECORDS 8u /* diagnostic: a scene of plain spheres alone is traced through the general primitive and
+                                 leaf records instead of the compact 64-byte sphere records (same image, for A/B runs) */
+
 typedef enum pt_render_mode {
     PT_MODE_OFFLINE = 0,    /* overwrite rgb with the mean of spp samples (src/trace.rs:178-181) */
     PT_MODE_REALTIME = 1    /* 80 % pixel skip + 1/n running blend capped at 1001 (src/trace.rs:144-177) */

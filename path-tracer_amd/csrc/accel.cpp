@@ -408,6 +408,31 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
         }
         out.prims.push_back(op);
     }
+    // Compact records, if the scene is plain spheres alone: untransformed, constant colour, one of the four surface
+    // materials, and sign bits free to carry the material kind.
+    out.spheres.clear();
+    bool compact = !flat.has_medium;
+    for (size_t k = 0; k < out.prims.size() && compact; ++k) {
+        const DevOp &op = out.prims[k];
+        const DevLeaf &lf = flat.leaves[op.leaf];
+        const double param = lf.mat_kind == PT_M_LAMBERTIAN ? lf.emissive
+                             : lf.mat_kind == PT_M_METAL    ? lf.fuzz
+                             : lf.mat_kind == PT_M_DIELECTRIC ? lf.ref_idx : 0.0;
+        compact = op_kind(op.kind) == OP_SPHERE && lf.full_count == 0 && lf.texture < 0 && lf.mat_kind >= PT_M_LAMBERTIAN &&
+                  lf.mat_kind <= PT_M_DIELECTRIC && std::isfinite(op.d[3]) && !std::signbit(op.d[3]) && std::isfinite(param) &&
+                  !std::signbit(param);
+        if (!compact) break;
+        const int code = lf.mat_kind - 1;
+        DevSphere sp;
+        for (int a = 0; a < 3; ++a) {
+            sp.c[a] = op.d[a];
+            sp.albedo[a] = lf.albedo[a];
+        }
+        sp.radius = (code & 1) ? -op.d[3] : op.d[3];
+        sp.param = (code & 2) ? -param : param;
+        out.spheres.push_back(sp);
+    }
+    if (!compact) out.spheres.clear();
     return true;
 }
 

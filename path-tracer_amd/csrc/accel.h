@@ -46,6 +46,8 @@ constexpr int kAccelMaxDepth = 28; // traversal stack entries per ray (32 KiB of
 struct Accel {
     std::vector<AccelNode> nodes; // nodes[0] is the root
     std::vector<DevOp> prims;     // primitive ops in leaf order, each carrying its FULL world -> primitive chain
+    // the same primitives as compact records (DevSphere), when every one of them qualifies; else empty
+    std::vector<DevSphere> spheres;
     int depth = 0;
     // for refitting on the device: where a node's own bounds are stored (parent * 2 + slot, -1 for the root) and
     // the nodes grouped by depth, deepest level first (level_start has one more entry than there are levels)

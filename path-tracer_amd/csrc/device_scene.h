@@ -79,6 +79,22 @@ struct DevLeaf { // 192 bytes
 };
 static_assert(sizeof(DevLeaf) == 192, "DevLeaf must be 192 bytes");
 
+// The compact record of a scene made of plain spheres alone (no wrapper, constant texture): 64 bytes that serve BOTH
+// the leaf test of the tree traversal and the shaded vertex, in the tree's leaf order, instead of a 64-byte DevOp for
+// the test and a 192-byte DevLeaf somewhere else in memory for the vertex. One million spheres: 64 MB beside 62 MB of
+// nodes, where ops + leaves + nodes were 318 MB (more than the 256-MB last-level cache holds). The material kind sits
+// in two sign bits that carry no other information: radius and param are non-negative in every scene that qualifies
+// (the host checks), and the sphere test reads the radius only squared.
+//   kind - 1 = sign(radius) | sign(param) << 1   with pt_material_kind LAMBERTIAN 1, DIFFUSE_LIGHT 2, METAL 3, DIELECTRIC 4
+//   param    = emissive (LAMBERTIAN), fuzz (METAL), ref_idx (DIELECTRIC), 0 (DIFFUSE_LIGHT)
+struct DevSphere { // 64 bytes
+    double c[3];
+    double radius;
+    double albedo[3]; // the constant texture's colour, or METAL's albedo
+    double param;
+};
+static_assert(sizeof(DevSphere) == 64, "DevSphere must be 64 bytes");
+
 enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_SPHERE = 1, LIGHT_RECT = 2 };
 struct DevLight { // 48 bytes: a shape of the light list (src/trace.rs:123-128)
     int32_t kind;

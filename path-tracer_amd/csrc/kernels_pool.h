@@ -276,7 +276,10 @@ template <> struct TreePoolTexLds<2> {
 // RT: a realtime frame (src/trace.rs:144-146: four of five pixels are skipped, by a draw keyed on seed, frame and
 // pixel). The path ids of a frame cover every pixel; a wave evaluates the skip draw of 64 ids at a time with all its
 // lanes, parks the ids that survive in LDS, and free lanes take their paths from there.
-template <int TEX, bool MEDIA, bool RT = false>
+// SPH: the scene is plain spheres alone and `prims` holds their compact records (DevSphere) in leaf order: the leaf
+// test and the vertex read the same 64 bytes, and the hit id is the record's index. Same arithmetic on the same
+// values as the general form: images are bit-identical.
+template <int TEX, bool MEDIA, bool RT = false, bool SPH = false>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
@@ -447,16 +450,25 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
             const int32_t ref = ~node;
             const int32_t first = ref >> 3, count = ref & 7;
             for (int32_t k = first; k < first + count; ++k) {
-                const DevOp op = prims[k];
                 double t = 0.0;
                 int sub = 0;
-                bool hit;
-                if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
-                    hit = medium_hit<false>(sv, op, o, d, inv, time, 0.001, closest, pkey, depth, t);
-                else hit = prim_hit<false>(sv, op, o, d, inv, time, 0.001, closest, t, sub);
-                if (hit) {
-                    closest = t;
-                    best = op.leaf | (sub << 28);
+                if constexpr (SPH) {
+                    const DevSphere *sp = (const DevSphere *)prims + k;
+                    // (the test reads the radius only squared: its sign bit, part of the material kind, drops out)
+                    if (sphere_t<false>(d3(sp->c[0], sp->c[1], sp->c[2]), sp->radius, o, d, 0.001, closest, t, sub)) {
+                        closest = t;
+                        best = k | (sub << 28);
+                    }
+                } else {
+                    const DevOp op = prims[k];
+                    bool hit;
+                    if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
+                        hit = medium_hit<false>(sv, op, o, d, inv, time, 0.001, closest, pkey, depth, t);
+                    else hit = prim_hit<false>(sv, op, o, d, inv, time, 0.001, closest, t, sub);
+                    if (hit) {
+                        closest = t;
+                        best = op.leaf | (sub << 28);
+                    }
                 }
             }
             node = sp ? stack[--sp][threadIdx.x] : kDone;
@@ -486,9 +498,30 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
             }
             if (ready) {
                 D3 no = d3(0, 0, 0), nd = d3(0, 0, 0), nbeta = d3(0, 0, 0), c;
-                const bool alive = shade_vertex<false, TEX, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn,
-                                                                            closest, best, depth, max_depth, flags, lx, ly,
-                                                                            lz, no, nd, nbeta, &c, noise_hit ? &turbulence : nullptr);
+                bool alive;
+                if constexpr (SPH) {
+                    // the leaf record the vertex code reads, rebuilt in registers from the compact record
+                    const DevSphere sp = ((const DevSphere *)prims)[li];
+                    DevLeaf lf;
+                    lf.kind = OP_SPHERE;
+                    lf.axis = 0;
+                    lf.mat_kind = 1 + (int32_t)((uint32_t)__double2hiint(sp.radius) >> 31) +
+                                  2 * (int32_t)((uint32_t)__double2hiint(sp.param) >> 31);
+                    lf.texture = -1;
+                    lf.full_start = lf.full_count = 0;
+                    lf.material = lf.op = lf.prim[0] = 0;
+                    lf.tex_flags = 0;
+                    lf.g[0] = sp.c[0]; lf.g[1] = sp.c[1]; lf.g[2] = sp.c[2];
+                    lf.g[3] = fabs(sp.radius);
+                    lf.albedo[0] = sp.albedo[0]; lf.albedo[1] = sp.albedo[1]; lf.albedo[2] = sp.albedo[2];
+                    lf.emissive = lf.ref_idx = lf.fuzz = fabs(sp.param);
+                    alive = shade_vertex<false, TEX, RAD_RETURN>(sv, lf, o, d, time, beta, pkey, pid, rn, closest, best, depth,
+                                                                    max_depth, flags, lx, ly, lz, no, nd, nbeta, &c, nullptr);
+                } else {
+                    alive = shade_vertex<false, TEX, RAD_RETURN>(sv, sv.leaves[li], o, d, time, beta, pkey, pid, rn, closest, best,
+                                                                    depth, max_depth, flags, lx, ly, lz, no, nd, nbeta, &c,
+                                                                    noise_hit ? &turbulence : nullptr);
+                }
                 if (depth == 0) sum = c; // the per-path sum of the other forms
                 else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
                 if (alive) {

@@ -181,6 +181,8 @@ struct pt_ctx {
     bool accel_ok = false;
     void *d_accel_nodes = nullptr, *d_accel_prims = nullptr, *d_accel_parent = nullptr, *d_accel_levels = nullptr;
     void *d_accel_nodes_q = nullptr; // the nodes in their 32-byte form (trees of kAccelQuantFrom nodes and more), else null
+    void *d_accel_spheres = nullptr; // the primitives as compact DevSphere records in leaf order (scenes of plain spheres alone), else null
+    bool compact_spheres = true;     // use them (PT_CFG_FAT_RECORDS turns them off, for A/B runs)
     AccelGrid accel_grid_q{};
     int32_t n_accel_nodes = 0;
     std::vector<std::pair<int32_t, int32_t>> accel_levels; // refit order (deepest level first): index ranges of d_accel_levels, or node id ranges when that is null
@@ -593,6 +595,16 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         };
         // (the 32-byte nodes the extend kernel reads on big trees cost this kernel 12 more registers of ray state: at
         // 128 VGPRs that is 80 B more scratch per lane, and the million-sphere render ran 588 -> 503 Mpaths/s)
+        if (ctx->d_accel_spheres && ctx->compact_spheres && ctx->tex == 0 && !media) {
+            // plain spheres alone: the compact records stand in for the primitive ops (and the leaf table)
+            auto launch_sph = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
+                                   (const DevOp *)ctx->d_accel_spheres, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
+                                   ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
+            };
+            if (realtime) launch_sph(k_tree_pool<0, false, true, true>);
+            else launch_sph(k_tree_pool<0, false, false, true>);
+        } else
         with_tex(ctx->tex, [&](auto T) {
             constexpr int kTex = decltype(T)::value;
             if (realtime) {
@@ -802,6 +814,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     ctx->seed = cfg->seed;
     ctx->flags = cfg->flags;
     ctx->exact = (cfg->flags & PT_CFG_EXACT) != 0;
+    ctx->compact_spheres = (cfg->flags & PT_CFG_FAT_RECORDS) == 0;
     pt_tuning tune;
     std::memset(&tune, 0, sizeof(tune));
     if (cfg->struct_size == sizeof(pt_config)) tune = cfg->tuning;
@@ -839,7 +852,7 @@ void pt_destroy(pt_ctx *ctx) {
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
                     ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
-                    ctx->d_accel_nodes_q, ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts,
+                    ctx->d_accel_nodes_q, ctx->d_accel_spheres, ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts,
                     ctx->d_stage[0], ctx->d_stage[1]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1003,12 +1016,17 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
     }
     // Everything else in fast mode is traced through a SAH tree over the same primitives (accel.h).
     ctx->accel_ok = false;
+    if (ctx->d_accel_spheres) {
+        (void)hipFree(ctx->d_accel_spheres);
+        ctx->d_accel_spheres = nullptr;
+    }
     if (!ctx->exact && !ctx->scan_list && ctx->use_accel) {
         Accel acc;
         std::string why;
         if (build_accel(f, acc, why)) {
             if ((rc = upload(ctx, &ctx->d_accel_nodes, acc.nodes.data(), acc.nodes.size())) != PT_OK) return rc;
             if ((rc = upload(ctx, &ctx->d_accel_prims, acc.prims.data(), acc.prims.size())) != PT_OK) return rc;
+            if ((rc = upload(ctx, &ctx->d_accel_spheres, acc.spheres.data(), acc.spheres.size())) != PT_OK) return rc;
             if ((rc = upload(ctx, &ctx->d_accel_parent, acc.parent_slot.data(), acc.parent_slot.size())) != PT_OK) return rc;
             if ((rc = upload(ctx, &ctx->d_accel_levels, acc.by_level.data(), acc.by_level.size())) != PT_OK) return rc;
             ctx->accel_levels.clear();
@@ -1550,9 +1568,9 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
     // scratch and the new arrays; whatever is still held here when the function returns is freed
     struct Held {
         void *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *temp = nullptr, *ranges = nullptr, *counter = nullptr;
-        void *prims = nullptr, *nodes = nullptr, *parent = nullptr;
+        void *prims = nullptr, *nodes = nullptr, *parent = nullptr, *spheres = nullptr;
         ~Held() {
-            for (void *p : {keys[0], keys[1], vals[0], vals[1], temp, ranges, counter, prims, nodes, parent})
+            for (void *p : {keys[0], keys[1], vals[0], vals[1], temp, ranges, counter, prims, nodes, parent, spheres})
                 if (p) (void)hipFree(p);
         }
     } h;
@@ -1577,6 +1595,12 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
                                                     (const uint32_t *)h.vals[0], (uint32_t *)h.vals[1], n, 0, 63, ctx->stream));
     hipLaunchKernelGGL(k_accel_gather_prims, dim3(grid_for(ctx, (uint64_t)n * 4)), dim3(kBlock), 0, ctx->stream,
                        (const DevOp *)ctx->d_accel_prims, (const uint32_t *)h.vals[1], (DevOp *)h.prims, n);
+    if (ctx->d_accel_spheres) { // the compact records follow their primitives (both are 64-byte records)
+        static_assert(sizeof(DevSphere) == sizeof(DevOp), "gathered by the same kernel");
+        HIP_TRY(ctx, counted_malloc(&h.spheres, (size_t)n * sizeof(DevSphere)));
+        hipLaunchKernelGGL(k_accel_gather_prims, dim3(grid_for(ctx, (uint64_t)n * 4)), dim3(kBlock), 0, ctx->stream,
+                           (const DevOp *)ctx->d_accel_spheres, (const uint32_t *)h.vals[1], (DevOp *)h.spheres, n);
+    }
     // the tree, level by level: node 0 is the root over the whole curve
     const BuildRange whole{0, n};
     const int32_t root_parent = -1, one = 1;
@@ -1601,6 +1625,7 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
     HIP_TRY(ctx, hipGetLastError());
     // hand the new arrays to the context (the old ones go with `h`) and fit the boxes
     std::swap(ctx->d_accel_prims, h.prims);
+    if (ctx->d_accel_spheres) std::swap(ctx->d_accel_spheres, h.spheres);
     std::swap(ctx->d_accel_nodes, h.nodes);
     std::swap(ctx->d_accel_parent, h.parent);
     if (ctx->d_accel_levels) (void)hipFree(ctx->d_accel_levels);
