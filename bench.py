@@ -305,6 +305,11 @@ def main():
     elapsed, st, image, ctx = timed_leg(pt.PT_CFG_PROFILE_STAGES | args.cfg_flags)
     value = paths_per_step * args.steps / elapsed / 1e6
     nan_frac = float(torch.isnan(image[..., :3]).any(dim=-1).float().mean().item()) if rank == 0 else 0.0
+    image_hash = None
+    if rank == 0:  # the image is a pure function of scene, seed, size and spp (never of GPU count, tiling or pass form)
+        import hashlib
+
+        image_hash = hashlib.sha1(image.cpu().numpy().tobytes()).hexdigest()[:16]
     ctx.close()
     del image
 
@@ -377,6 +382,7 @@ def main():
                 "present": args.present,
                 "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
                 "nan_pixel_fraction": nan_frac,
+                "image_sha1_16": image_hash,
                 "book_semantics": bool(args.book_semantics),
                 "arithmetic": "f64 throughout (rays, intersections, sampling, pdf values, weights, throughput); quotients and "
                               "roots by Newton-refined hardware reciprocals, a*b+c fused, sin/cos by quadrant reduction + "
