@@ -417,18 +417,6 @@ __device__ __forceinline__ bool accel_box(const float *lo, const float *hi, D3 o
     return tn <= tf;
 }
 
-// experiment: one FMA per plane, plane * (1 / d) - o / d
-__device__ __forceinline__ bool accel_box_fma(const float *lo, const float *hi, D3 inv, D3 oi, double t_min, double t_max,
-                                              double &t_near) {
-    const double x0 = __builtin_fma((double)lo[0], inv.x, oi.x), x1 = __builtin_fma((double)hi[0], inv.x, oi.x);
-    const double y0 = __builtin_fma((double)lo[1], inv.y, oi.y), y1 = __builtin_fma((double)hi[1], inv.y, oi.y);
-    const double z0 = __builtin_fma((double)lo[2], inv.z, oi.z), z1 = __builtin_fma((double)hi[2], inv.z, oi.z);
-    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), t_min));
-    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), t_max));
-    t_near = tn;
-    return tn <= tf;
-}
-
 // The slab tests of a 32-byte node (AccelNodeQ). A plane is gmin + q cell, so its distance along the ray is
 // (gmin + q cell - o) inv = q (cell inv) + (gmin - o) inv: one FMA per plane with two per-ray constants per axis.
 // 1 / d is clamped to +-1e300 for them: along an axis the ray runs parallel to, an infinite factor would turn every

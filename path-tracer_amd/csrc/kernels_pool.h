@@ -276,11 +276,14 @@ template <> struct TreePoolTexLds<2> {
 // RT: a realtime frame (src/trace.rs:144-146: four of five pixels are skipped, by a draw keyed on seed, frame and
 // pixel). The path ids of a frame cover every pixel; a wave evaluates the skip draw of 64 ids at a time with all its
 // lanes, parks the ids that survive in LDS, and free lanes take their paths from there.
+#ifndef PT_SPH_WAVES
+#define PT_SPH_WAVES 4 // waves per SIMD of the variant for plain spheres
+#endif
 // SPH: the scene is plain spheres alone and `prims` holds their compact records (DevSphere) in leaf order: the leaf
 // test and the vertex read the same 64 bytes, and the hit id is the record's index. Same arithmetic on the same
 // values as the general form: images are bit-identical.
 template <int TEX, bool MEDIA, bool RT = false, bool SPH = false>
-__global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
+__global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH_WAVES : PT_SHADE_WAVES)) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk_arg) {
@@ -311,8 +314,6 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
     uint32_t pid = 0, rn = 0, depth = 0, segments = 0;
     int32_t best = -1, node = kDone;
     int sp = 0;
-    int32_t pend = kDone, pf0 = 0, pf1 = 0, sink = 0; // experiments (PT_EXP)
-    D3 oi = o;
 #ifdef PT_POOL_TIMING
     long long tm_refill = 0, tm_inner = 0, tm_leaf = 0, tm_shade = 0, tm_rounds = 0, tm_shades = 0, tm_lanes = 0, tm0 = clock64();
 #define PT_TICK(acc) { long long t_ = clock64(); acc += t_ - tm0; tm0 = t_; }
@@ -322,7 +323,6 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
 #endif
     auto start_ray = [&]() { // (o, d) hold a new ray
         inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-        oi = d3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
         closest = kF64Max;
         best = -1;
         sp = 0;
@@ -428,88 +428,27 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
         }
         PT_TICK(tm_refill)
         // traversal: inner nodes for as long as at least `inner_min` lanes are on one, then the leaves
-#ifndef PT_EXP
-#define PT_EXP 0
-#endif
         for (;;) {
             if (has && node >= 0) {
                 const AccelNode &nd = nodes[node];
                 double t0, t1;
-#if PT_EXP & 4
-                // touches of both children's records, issued once the whole node has arrived and BEFORE the slab tests (every
-                // field passes through the statement, so the compiler has waited for all of them, none of its later waits
-                // can mean these two loads, and no test can be scheduled ahead of them); the values are never used, and
-                // loads return in order, so the next node's data implies these have landed
-                const int32_t c0 = nd.child[0], c1 = nd.child[1];
-                float l0[3] = {nd.lo[0][0], nd.lo[0][1], nd.lo[0][2]}, u0[3] = {nd.hi[0][0], nd.hi[0][1], nd.hi[0][2]};
-                float l1[3] = {nd.lo[1][0], nd.lo[1][1], nd.lo[1][2]}, u1[3] = {nd.hi[1][0], nd.hi[1][1], nd.hi[1][2]};
-                {
-                    const AccelNode *a0 = nodes + (c0 < 0 ? 0 : c0), *a1 = nodes + (c1 < 0 ? 0 : c1);
-                    asm volatile("global_load_dword %0, %13, off offset:56\n\tglobal_load_dword %0, %14, off offset:56"
-                                 : "+v"(sink), "+v"(l0[0]), "+v"(l0[1]), "+v"(l0[2]), "+v"(u0[0]), "+v"(u0[1]), "+v"(u0[2]),
-                                   "+v"(l1[0]), "+v"(l1[1]), "+v"(l1[2]), "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2])
-                                 : "v"(a0), "v"(a1)
-                                 : "memory");
-                }
-                const bool h0 = accel_box(l0, u0, o, inv, 0.001, closest, t0);
-                const bool h1 = accel_box(l1, u1, o, inv, 0.001, closest, t1);
-#else
-#if PT_EXP & 2
-                const bool h0 = accel_box_fma(nd.lo[0], nd.hi[0], inv, oi, 0.001, closest, t0);
-                const bool h1 = accel_box_fma(nd.lo[1], nd.hi[1], inv, oi, 0.001, closest, t1);
-#else
                 const bool h0 = accel_box(nd.lo[0], nd.hi[0], o, inv, 0.001, closest, t0);
                 const bool h1 = accel_box(nd.lo[1], nd.hi[1], o, inv, 0.001, closest, t1);
-#endif
                 const int32_t c0 = nd.child[0], c1 = nd.child[1];
-#endif
                 if (h0 && h1) {
                     const bool first0 = t0 <= t1;
                     stack[sp++][threadIdx.x] = first0 ? c1 : c0;
-#if PT_EXP & 8
-                    {
-                        const int32_t far = first0 ? c1 : c0;
-                        const AccelNode *a0 = nodes + (far < 0 ? 0 : far);
-                        asm volatile("global_load_dword %0, %1, off offset:56" : "+v"(sink) : "v"(a0) : "memory");
-                    }
-#endif
                     node = first0 ? c0 : c1;
                 } else if (h0 || h1) {
                     node = h0 ? c0 : c1;
                 } else {
                     node = sp ? stack[--sp][threadIdx.x] : kDone;
                 }
-#if PT_EXP & 1
-                // a lane that reaches a leaf sets it aside (one at most) and goes on with its stack
-                if (node < 0 && node != kDone && pend == kDone) {
-                    pend = node;
-                    node = sp ? stack[--sp][threadIdx.x] : kDone;
-                }
-#endif
             }
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(has && node >= 0));
             if (n_inner == 0 || n_inner < inner_min) break;
         }
-#if PT_EXP & 12
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory"); // no touch is in flight when its register is let go
-#endif
         PT_TICK(tm_inner)
-#if PT_EXP & 1
-        if (has && pend != kDone) { // the leaf set aside, then (below) the one the lane stands on
-            const int32_t ref = ~pend;
-            const int32_t first = ref >> 3, count = ref & 7;
-            for (int32_t k = first; k < first + count; ++k) {
-                double t = 0.0;
-                int sub = 0;
-                const DevSphere *sp_ = (const DevSphere *)prims + k;
-                if (sphere_t<false>(d3(sp_->c[0], sp_->c[1], sp_->c[2]), sp_->radius, o, d, 0.001, closest, t, sub)) {
-                    closest = t;
-                    best = k | (sub << 28);
-                }
-            }
-            pend = kDone;
-        }
-#endif
         if (has && node < 0 && node != kDone) {
             const int32_t ref = ~node;
             const int32_t first = ref >> 3, count = ref & 7;
@@ -616,6 +555,5 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVE
                    (double)c[3 * k] / tm_shades, (double)c[3 * k + 1] / tm_shades, (double)c[3 * k + 2] / (double)(c[3 * k + 1] ? c[3 * k + 1] : 1));
     }
 #endif
-    if (sink == 0x7fffffff && pf0 == 0x12345 && pf1 == 0x54321) segments += 1; // experiments: keeps the touches alive
     if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments); // as in k_path_pool
 }

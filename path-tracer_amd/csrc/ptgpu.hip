@@ -567,7 +567,8 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     }
     if (tree) {
         const uint32_t tiles = (n + 63u) / 64u;
-        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex == 2 ? PT_TREE_UV_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
+        const bool spheres = ctx->d_accel_spheres && ctx->compact_spheres && ctx->tex == 0 && !ctx->view.has_medium;
+        const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex == 2 ? PT_TREE_UV_WAVES : spheres ? PT_SPH_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         const uint32_t waves = grid * kWavesPerBlock;
         const uint32_t fair = ((realtime ? (n + waves - 1u) / waves : n / (waves * 4u)) + 63u) & ~63u; // as for the path pool
@@ -595,7 +596,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         };
         // (the 32-byte nodes the extend kernel reads on big trees cost this kernel 12 more registers of ray state: at
         // 128 VGPRs that is 80 B more scratch per lane, and the million-sphere render ran 588 -> 503 Mpaths/s)
-        if (ctx->d_accel_spheres && ctx->compact_spheres && ctx->tex == 0 && !media) {
+        if (spheres) {
             // plain spheres alone: the compact records stand in for the primitive ops (and the leaf table)
             auto launch_sph = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
