@@ -9,8 +9,10 @@ to rank 0 inside the timed region. The RNG is keyed by global pixel and sample i
 on N.
 
 Prints ONE JSON line on rank 0: the throughput (`value`), the same workload in exact mode, the extend stage alone on
-fixed ray batches (Mrays/s with id / t agreement against the CPU oracle), the roofline of the dominant kernel against
-the FP64 vector peak, and the CPU oracle timed on the host cores.
+fixed ray batches (Mrays/s with id / t agreement against the CPU oracle, and its bytes per ray against the HBM peak), the
+roofline of the dominant kernel against the FP64 vector peak, the other single-GPU configurations of the reference
+(`config.workloads`: RTiOW, the final scene and the smoke box in reference and book semantics, one million spheres), each
+with its own throughput, segments per path, NaN fraction and roofline block, and the CPU oracle timed on the host cores.
 """
 import argparse
 import importlib
@@ -27,6 +29,118 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X: 256 CUs x 4 SIMDs x 16 f64 FMA lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 SEED = 0x5EED0001
+
+# The other single-GPU configurations: (label, recipe, recipe parameter, width, height, spp, max_depth, book semantics).
+# Book semantics (PT_RENDER_BOOK_SEMANTICS with the scene's own light as the light shape, recipe parameter 1) is the
+# headline of the two media scenes: in reference semantics the final scene's image is NaN in every pixel and the smoke
+# box's in 87 % of them (Isotropic has no scattering pdf in the reference, src/material.rs:142-144,346-352).
+WORKLOADS = [
+    ("C1 RTiOW random_scene (src/lib.rs:713-765)", "random_scene", 0, 1200, 800, 100, 50, False),
+    ("C3 final_book_two, reference semantics (src/lib.rs:990-1077)", "final_book_two", 0, 1024, 1024, 64, 50, False),
+    ("C3 final_book_two, book semantics", "final_book_two", 1, 1024, 1024, 64, 50, True),
+    ("C3 cornell_smoke, reference semantics (src/lib.rs:894-988)", "cornell_smoke", 0, 1024, 1024, 64, 50, False),
+    ("C3 cornell_smoke, book semantics", "cornell_smoke", 1, 1024, 1024, 64, 50, True),
+    ("C4 one million spheres (sphere_cloud)", "sphere_cloud", 1000000, 3840, 2160, 16, 10, False),
+]
+
+
+def load_model(entry):
+    """Per-segment counts of a workload's pass kernel from the committed counter passes (profiles/pmc_model.json, written
+    by tools/pmc_model.py from a rocprofv3 --pmc summary under profiles/)."""
+    path = os.path.join(ROOT, "profiles", "pmc_model.json")
+    if not os.path.exists(path):
+        return {}
+    return json.load(open(path)).get(entry, {})
+
+
+def roofline_block(pt, st, model):
+    """Roofline of the pass kernel of the run `st` describes: FP64 instructions issued per segment (ADD + MUL + 2 FMA,
+    x 64 lanes) and HBM bytes per segment (2 x FETCH_SIZE + WRITE_SIZE) from the committed counter pass, scaled to this
+    run's segments per launch and divided by this run's launch time (HIP events on the library's stream)."""
+    n_launch = max(int(st.profiled_bounce_launches), 1)
+    seg = float(st.profiled_segments)
+    form = int(st.last_pass_form)
+    one_launch = form in (pt.PT_PASS_PATH_POOL, pt.PT_PASS_TREE_POOL, pt.PT_PASS_PERSISTENT)
+    dom_ms = st.ms_shade if (one_launch or st.ms_shade >= st.ms_extend) else st.ms_extend
+    kernel = {pt.PT_PASS_PATH_POOL: "k_path_pool", pt.PT_PASS_TREE_POOL: "k_tree_pool",
+              pt.PT_PASS_PERSISTENT: "k_trace_persistent"}.get(form, "k_shade" if st.ms_shade >= st.ms_extend else "k_extend*")
+    if model and model.get("kernel_full_name", kernel).split("<")[0] != kernel:
+        model = {}  # the committed counters describe another kernel than the one that ran
+    units_per_launch = seg / n_launch
+    launch_s = dom_ms / n_launch * 1e-3
+    flop_unit = model.get("fp64_flop_issued_per_unit")
+    achieved = flop_unit * units_per_launch / launch_s / 1e12 if (flop_unit and launch_s > 0) else None
+    hbm_unit = model.get("hbm_bytes_per_unit")
+    traffic = hbm_unit * units_per_launch if hbm_unit is not None else None
+    return {
+        "bound": "fp64_valu",
+        "kernel": model.get("kernel_full_name", kernel),
+        "achieved": achieved,
+        "peak": FP64_VECTOR_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": (achieved / FP64_VECTOR_PEAK_TFLOPS) if achieved is not None else None,
+        "traffic": traffic,
+        "traffic_note": "bytes the L2s request from the fabric per launch (2 x FETCH_SIZE + WRITE_SIZE): hits in the 256-MiB "
+                        "last-level cache are counted, and the factor 2 is calibrated for coalesced 16-byte-per-lane reads only "
+                        "(divergent node fetches of the tree kernels may be counted up to twice)",
+        "avg_launch_ms": dom_ms / n_launch,
+        "units_per_launch": units_per_launch,
+        "unit_name": "path segment as the GPU traces it (fast mode stops a path whose throughput is exactly zero; the "
+                     "reference follows it to the depth cap: see segments_per_path against cpu_baseline.S)",
+        "fp64_flop_issued_per_unit": flop_unit,
+        "hbm_bytes_per_unit": hbm_unit,
+        "hbm_GBs": (traffic / launch_s / 1e9) if (traffic is not None and launch_s > 0) else None,
+        "hbm_frac_of_peak": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if (traffic is not None and launch_s > 0) else None,
+        "valu_busy_frac": model.get("valu_busy_frac"),
+        "mean_active_lanes": model.get("mean_active_lanes"),
+        "valu_insts_per_unit": model.get("valu_insts_per_unit"),
+        "fp64_share_of_valu_insts": model.get("fp64_share_of_valu_insts"),
+        "wait_frac_of_wave_cycles": model.get("wait_frac_of_wave_cycles"),
+        "l2_hit_frac": model.get("l2_hit_frac"),
+        "model_source": model.get("source"),
+        "profiled_launches": n_launch,
+        "Msegments_s": seg / (dom_ms * 1e-3) / 1e6 if dom_ms > 0 else None,
+        "stage_ms": {"raygen": st.ms_raygen, "extend": st.ms_extend, "shade_or_pass_kernel": st.ms_shade,
+                     "resolve": st.ms_resolve},
+    }
+
+
+def workload_leg(pt, torch, device, spec, steps, warmup, paths_in_flight):
+    """One of the other configurations on one GPU: warm-up renders, then `steps` timed renders between synchronisations."""
+    import hashlib
+
+    label, name, param, W, H, spp, depth, book = spec
+    scene = pt.Scene.named(name, W / H, seed=SEED, param=param)
+    ctx = pt.Context(device=device, seed=SEED, max_paths_in_flight=paths_in_flight, flags=pt.PT_CFG_PROFILE_STAGES, profile_period=1)
+    ctx.upload(scene)
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{device}")
+    ctx.bind_image(image.data_ptr(), W, H)
+    rflags = pt.PT_RENDER_BOOK_SEMANTICS if book else 0
+    for k in range(warmup):
+        ctx.render(W, H, spp, depth, frame=k, flags=rflags)
+    ctx.stats_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ctx.render(W, H, spp, depth, frame=warmup + k, flags=rflags)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    out = {
+        "workload": f"{label}: {name} {W}x{H} @ {spp} spp, max_depth {depth}",
+        "Mpaths_s": float(W) * H * spp * steps / elapsed / 1e6,
+        "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "book_semantics": book,
+        "headline_of_its_config": book or name in ("random_scene", "sphere_cloud"),
+        "segments_per_path": float(st.segments) / max(float(st.paths), 1.0),
+        "nan_pixel_fraction": float(torch.isnan(image[..., :3]).any(dim=-1).float().mean().item()),
+        "image_sha1_16": hashlib.sha1(image.cpu().numpy().tobytes()).hexdigest()[:16],
+        "roofline": roofline_block(pt, st, load_model(name + (":book" if book else ""))),
+    }
+    ctx.close()
+    return out
 
 
 def parse_args(argv=None):
@@ -142,6 +256,37 @@ def extend_leg(pt, ob, torch, np, device, name, param, check_rays):
                       "id_agreement": float(same.mean()), "max_rel_t_err": float(rel.max()) if rel.size else 0.0,
                       "hit_fraction": float((ref["prim"] >= 0).mean())}
     ctx.close()
+    # Roofline of the extend launches against HBM: node records read (V) and primitives tested (P) per ray, counted by the
+    # traversal itself on the first 65 536 rays of each batch (PT_CFG_COUNT_ACCEL), priced at the size of the records the
+    # timed kernel reads, plus the ray in (7 f64) and the hit out (f64 + i32).
+    cctx = pt.Context(device=device, seed=SEED, max_paths_in_flight=1 << 16, flags=pt.PT_CFG_COUNT_ACCEL)
+    cctx.upload(scene)
+    n_nodes = scene.accel_info()["n_nodes"]
+    for label, rays in (("primary", primary), ("secondary", secondary)):
+        m = min(len(rays), 1 << 16)
+        cctx.stats_reset()
+        cctx.intersect(rays[:m], medium_seed=5)
+        cst = cctx.stats()
+        V, P = cst.node_visits / m, cst.prim_tests / m
+        tree = V > 0
+        node_bytes = (32 if n_nodes >= 32768 else 64) if tree else 0  # big trees are read in their 32-byte form
+        compulsory = 56 + 12
+        model_bytes = compulsory + node_bytes * V + 64 * P
+        rate = out[label]["Mrays_s"] * 1e6
+        out[label]["roofline"] = {
+            "bound": "hbm", "kernel": "k_extend_accel_pool" if tree else "k_extend_list",
+            "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "node_visits_per_ray": V, "prim_tests_per_ray": P, "counted_rays": int(m),
+            "bytes_per_ray": model_bytes, "bytes_per_ray_compulsory": compulsory,
+            "achieved": rate * model_bytes / 1e9, "frac": rate * model_bytes / 1e9 / HBM_PEAK_GBS,
+            "achieved_compulsory": rate * compulsory / 1e9, "frac_compulsory": rate * compulsory / 1e9 / HBM_PEAK_GBS,
+            "note": ("records of 32 B per node visit and 64 B per primitive test, as the kernel reads them; most of these reads "
+                     "are served by L2 and the last-level cache, so frac prices the memory system as a whole, not HBM alone")
+            if tree else
+            ("a list scene: every ray is tested against every primitive, and the records come through the scalar cache "
+             "once per wave, not once per ray; only frac_compulsory (ray in, hit out) is HBM traffic"),
+        }
+    cctx.close()
     return out
 
 
@@ -335,27 +480,12 @@ def main():
             if args.extend_cloud > 0:
                 extend[f"sphere_cloud_{args.extend_cloud}"] = extend_leg(pt, ob, torch, np, local_rank, "sphere_cloud",
                                                                          args.extend_cloud, 1 << 16)
-        n_launch = max(int(st.profiled_bounce_launches), 1)
-        seg = float(st.profiled_segments)
-        form = int(st.last_pass_form)
-        one_launch = form in (pt.PT_PASS_PATH_POOL, pt.PT_PASS_TREE_POOL, pt.PT_PASS_PERSISTENT)
-        dom_ms = st.ms_shade if (one_launch or st.ms_shade >= st.ms_extend) else st.ms_extend
-        kernel = {pt.PT_PASS_PATH_POOL: "k_path_pool", pt.PT_PASS_TREE_POOL: "k_tree_pool",
-                  pt.PT_PASS_PERSISTENT: "k_trace_persistent"}.get(form, "k_shade" if st.ms_shade >= st.ms_extend else "k_extend*")
-        # Per-segment counts of the dominant kernel from the committed PMC passes of the headline workload
-        # (profiles/pmc_model.json, written by tools/pmc_model.py from a rocprofv3 --pmc summary): FP64 instructions
-        # issued (ADD + MUL + 2 FMA, x 64 lanes) and HBM bytes (2 x FETCH_SIZE + WRITE_SIZE). Scaled to this run's
-        # segments per launch and divided by this run's launch time (HIP events on the library's stream).
-        model = {}
-        path = os.path.join(ROOT, "profiles", "pmc_model.json")
-        if os.path.exists(path) and args.scene == "cornell_box" and not args.realtime:
-            model = json.load(open(path)).get(kernel, {})
-        units_per_launch = seg / n_launch
-        launch_s = dom_ms / n_launch * 1e-3
-        flop_unit = model.get("fp64_flop_issued_per_unit")
-        achieved = flop_unit * units_per_launch / launch_s / 1e12 if (flop_unit and launch_s > 0) else None
-        hbm_unit = model.get("hbm_bytes_per_unit")
-        traffic = hbm_unit * units_per_launch if hbm_unit is not None else None
+        model = load_model("k_path_pool") if (args.scene == "cornell_box" and not args.realtime) else \
+            load_model(args.scene + (":book" if args.book_semantics else "")) if not args.realtime else {}
+        roofline = roofline_block(pt, st, model)
+        workloads = None
+        if world == 1 and not args.no_workloads and not args.realtime:
+            workloads = [workload_leg(pt, torch, local_rank, spec, 2, 1, min(args.paths_in_flight, 1 << 27)) for spec in WORKLOADS]
         result = {
             "metric": f"Mpaths/sec (traced pixels x spp / s), {args.scene} realtime frames" if args.realtime
             else "Mpaths/sec (pixels x spp / s), Cornell box offline render; Mrays/s BVH extend in config.extend" if args.scene == "cornell_box"
@@ -371,6 +501,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "gather": (("pt_group_gather (RCCL inside the library)" if args.gather == "capi" else "torch.distributed.gather")
+                       if world > 1 else None),
             "config": {
                 "workload": f"{args.scene} {W}x{H} @ {args.spp} spp, max_depth {args.max_depth}, "
                             f"{'realtime progressive frames (80 % pixel skip), ' if args.realtime else ''}"
@@ -390,32 +522,10 @@ def main():
                 "exact_mode_Mpaths_s": exact_value,
                 "exact_mode_ms_per_step": exact_ms,
                 "extend": extend,
+                "workloads": workloads,
+                "gather": (args.gather if world > 1 else None),
             },
-            "roofline": {
-                "bound": "fp64_valu",
-                "kernel": kernel,
-                "achieved": achieved,
-                "peak": FP64_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": (achieved / FP64_VECTOR_PEAK_TFLOPS) if achieved is not None else None,
-                "traffic": traffic,
-                "avg_launch_ms": dom_ms / n_launch,
-                "units_per_launch": units_per_launch,
-                "unit_name": "path segment",
-                "fp64_flop_issued_per_unit": flop_unit,
-                "hbm_bytes_per_unit": hbm_unit,
-                "hbm_GBs": (traffic / launch_s / 1e9) if (traffic is not None and launch_s > 0) else None,
-                "hbm_frac_of_peak": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if (traffic is not None and launch_s > 0) else None,
-                "valu_busy_frac": model.get("valu_busy_frac"),
-                "mean_active_lanes": model.get("mean_active_lanes"),
-                "valu_insts_per_unit": model.get("valu_insts_per_unit"),
-                "fp64_share_of_valu_insts": model.get("fp64_share_of_valu_insts"),
-                "model_source": model.get("source"),
-                "profiled_launches": n_launch,
-                "Msegments_s": seg / (dom_ms * 1e-3) / 1e6 if dom_ms > 0 else None,
-                "stage_ms": {"raygen": st.ms_raygen, "extend": st.ms_extend, "shade_or_pass_kernel": st.ms_shade,
-                             "resolve": st.ms_resolve},
-            },
+            "roofline": roofline,
         }
         if cpu is not None:
             result["cpu_baseline"] = cpu

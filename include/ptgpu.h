@@ -214,6 +214,11 @@ typedef struct pt_config {
 #define PT_CFG_FAT_RECORDS 8u /* diagnostic: a scene of plain spheres alone is traced through the general primitive and
                                  leaf records instead of the compact 64-byte sphere records (same image, for A/B runs) */
 
+#define PT_CFG_COUNT_ACCEL 16u /* diagnostic, fast mode: pt_intersect* count the node records read and the primitives
+                                  tested in the fast-mode tree (pt_stats.node_visits / prim_tests); the batch then runs
+                                  through the ray-per-thread form of the traversal, which visits what the lane pool visits.
+                                  PT_CFG_COUNT_TRAVERSAL counts the walk of the reference's own tree instead */
+
 typedef enum pt_render_mode {
     PT_MODE_OFFLINE = 0,    /* overwrite rgb with the mean of spp samples (src/trace.rs:178-181) */
     PT_MODE_REALTIME = 1    /* 80 % pixel skip + 1/n running blend capped at 1001 (src/trace.rs:144-177) */

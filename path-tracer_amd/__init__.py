@@ -44,6 +44,7 @@ PT_CFG_PROFILE_STAGES = 1
 PT_CFG_COUNT_TRAVERSAL = 2
 PT_CFG_EXACT = 4
 PT_CFG_FAT_RECORDS = 8
+PT_CFG_COUNT_ACCEL = 16
 
 # pt_hitable_kind
 H_SPHERE, H_MOVING_SPHERE, H_RECT, H_BOX, H_LIST, H_FLIP, H_TRANSLATE, H_ROTATE_Y, H_MEDIUM, H_BVH = range(1, 11)

@@ -449,7 +449,9 @@ __device__ __forceinline__ void accel_boxes_q(const AccelNodeQ &n, const QuantRa
     h1 = t1 <= f1;
 }
 
-template <bool MEDIA>
+// COUNT: node records read and primitives tested are added to a.counters (PT_CFG_COUNT_ACCEL). The lane pool form
+// below walks the same tree in the same order ray by ray, so the counts describe both.
+template <bool MEDIA, bool COUNT = false>
 __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q, SceneView sv, const AccelNode *nodes,
                                                          const DevOp *prims, ExtendArgs a) {
     __shared__ int32_t stack[kAccelMaxDepth][kBlock]; // [depth][thread]: conflict-free
@@ -467,8 +469,10 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q,
         const D3 inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
         double closest = a.t_max;
         int32_t best = -1;
+        uint32_t my_nodes = 0, my_prims = 0;
         // tests the primitives of a leaf child
         auto leaf = [&](int32_t first, int32_t count) {
+            if constexpr (COUNT) my_prims += (uint32_t)count;
             for (int32_t k = first; k < first + count; ++k) {
                 const DevOp op = prims[k];
                 double t = 0.0;
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q,
         const bool traceable = probe == probe && fabs(probe) <= kF64Max;
         while (traceable) {
             const AccelNode &n = nodes[node];
+            if constexpr (COUNT) my_nodes += 1;
             double t0, t1;
             bool h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
             bool h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
@@ -528,6 +533,10 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel(Queue q,
         }
         a.hit_t[i] = closest;
         a.hit_id[i] = best;
+        if constexpr (COUNT) {
+            atomicAdd(&a.counters->node_visits, (unsigned long long)my_nodes);
+            atomicAdd(&a.counters->prim_tests, (unsigned long long)my_prims);
+        }
     }
 }
 

@@ -367,7 +367,11 @@ D3 hunit(D3 a) {
 
 template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
-    if (!X && ctx->accel_ok && a.counters == nullptr && ctx->accel_pool && !(ctx->accel_pool_from > a.depth && a.key_mode == 0)) {
+    if (!X && ctx->accel_ok && a.counters != nullptr && (ctx->flags & PT_CFG_COUNT_ACCEL)) {
+        // diagnostic: the ray-per-thread form with its node and primitive counters on
+        hipLaunchKernelGGL((k_extend_accel<MEDIA, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
+                           (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a);
+    } else if (!X && ctx->accel_ok && a.counters == nullptr && ctx->accel_pool && !(ctx->accel_pool_from > a.depth && a.key_mode == 0)) {
         grid = std::min(grid, ctx->n_cu * (MEDIA ? 4 : 5) * (int)ctx->accel_grid); // what is resident at once
         if (ctx->d_accel_nodes_q)
             hipLaunchKernelGGL((k_extend_accel_pool<MEDIA, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
@@ -1227,7 +1231,7 @@ int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats) {
 // hit_t / hit_id. `counts` is the queue's fill count (one word on the device), written here. Nothing is allocated.
 static int extend_batch(pt_ctx *ctx, const Queue &q, uint32_t shard_cap, uint32_t *counts, double *hit_t, int32_t *hit_id,
                         size_t n, double t_min, double t_max, uint64_t medium_seed, int repeats, double *mean_ms_out) {
-    const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
+    const bool count = (ctx->flags & (PT_CFG_COUNT_TRAVERSAL | PT_CFG_COUNT_ACCEL)) != 0;
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)counts, (int)(uint32_t)n, 1, ctx->stream));
     const int g = grid_for(ctx, n);
     ExtendArgs ea;

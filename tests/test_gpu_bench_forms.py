@@ -223,3 +223,25 @@ def test_compact_sphere_records_give_the_same_image(case):
         ref, _ = ob.render(scene.desc(), scene.camera, w, h, spp, depth, seed=0x5EED0001, threads=4)
         close, rel_rmse, nan_same = _compare(images["compact"][0], ref)
         assert nan_same >= 0.99 and close >= 0.98, (close, rel_rmse, nan_same)
+
+
+def test_tree_traversal_counters():
+    """PT_CFG_COUNT_ACCEL: node records read and primitives tested per ray in the fast-mode tree, the figures bench.py
+    prices the extend launches with. The counting form returns the hits of the timed form, every ray reads at least the
+    root, and a ray that hits something has tested at least one primitive."""
+    scene = ptgpu.Scene.named("random_scene", 1.5)
+    pix = np.arange(128 * 96, dtype=np.uint64)
+    rays = ob.camera_rays(scene.camera, 128, 96, pix, np.zeros(128 * 96, dtype=np.uint32))
+    plain = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 16)
+    plain.upload(scene)
+    want = plain.intersect(rays)
+    plain.close()
+    ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 16, flags=ptgpu.PT_CFG_COUNT_ACCEL)
+    ctx.upload(scene)
+    got = ctx.intersect(rays)
+    st = ctx.stats()
+    ctx.close()
+    assert (got["prim"] == want["prim"]).all() and (got["t"].view(np.uint64) == want["t"].view(np.uint64)).all()
+    n, n_hit = len(rays), int((want["prim"] >= 0).sum())
+    assert st.node_visits >= n and st.prim_tests >= n_hit
+    assert st.node_visits / n < 2 * np.log2(scene.accel_info()["n_nodes"]) + 20  # a tree walk, not a scan

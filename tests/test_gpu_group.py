@@ -91,3 +91,4 @@ def test_bench_multi_rank_rehearsal():
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 2
     assert line["value"] > 0 and line["dtype"] == "f64" and line["roofline"]["bound"] == "fp64_valu"
     assert line["config"]["nan_pixel_fraction"] == 0.0
+    assert line["gather"] == "torch.distributed.gather"  # the line says which gather moved the rows

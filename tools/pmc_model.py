@@ -2,7 +2,9 @@
 """Per-segment model of a kernel from the PMC summary tools/run_pmc.sh writes (one rocprofv3 --pmc run per counter
 set) -> profiles/pmc_model.json, which bench.py scales to the live run.
 
-usage: pmc_model.py <gpurun_out/pmc_TAG> <kernel short name, e.g. k_path_pool> <source note>
+usage: pmc_model.py <gpurun_out/pmc_TAG> <kernel short name, e.g. k_path_pool> <source note> [entry name]
+       (entry name: the key in pmc_model.json, by default the kernel's short name; bench.py looks its workloads up by
+       "<scene>" / "<scene>:book")
 
   fp64_flop_issued_per_unit  (ADD_F64 + MUL_F64 + 2 FMA_F64 wave-instructions) x 64 lanes / segments
   hbm_bytes_per_unit         (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / segments   (gfx950 reports half the bytes of
@@ -17,6 +19,7 @@ import re
 import sys
 
 out_dir, kernel, note = sys.argv[1], sys.argv[2], sys.argv[3]
+entry_name = sys.argv[4] if len(sys.argv) > 4 else kernel
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = [r for r in csv.DictReader(open(os.path.join(out_dir, "summary.csv"))) if r["kernel"].split("<")[0] == kernel]
 if not rows:
@@ -45,9 +48,11 @@ entry = {
     "trans_f64_share_of_valu_insts": f("SQ_INSTS_VALU_TRANS_F64") / f("SQ_INSTS_VALU"),
     "int32_share_of_valu_insts": f("SQ_INSTS_VALU_INT32") / f("SQ_INSTS_VALU"),
     "wait_frac_of_wave_cycles": f("SQ_WAIT_ANY") / f("SQ_WAVE_CYCLES"),
+    "l2_hit_frac": f("TCC_HIT_sum") / f("TCC_REQ_sum") if f("TCC_REQ_sum") else None,
+    "kernel_ms_in_counter_pass": f("GRBM_GUI_ACTIVE") / 8 / 2.4e6,
 }
 path = os.path.join(ROOT, "profiles", "pmc_model.json")
 model = json.load(open(path)) if os.path.exists(path) else {}
-model[kernel] = entry
+model[entry_name] = entry
 json.dump(model, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(entry, indent=1))
