@@ -337,7 +337,9 @@ def main():
 
     def timed_leg(flags):
         """W warm-up steps, then K steps between barriers, max over ranks: (seconds, stats, image tensor, ctx)."""
-        ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=args.paths_in_flight, flags=flags)
+        # a rank traces every world-th row: its passes never hold more than its share of the paths
+        share = W * ((H + world - 1) // world) * args.spp
+        ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=max(1 << 16, min(args.paths_in_flight, share)), flags=flags)
         ctx.upload(scene)
         # the image lives in a torch tensor (rank 0 inspects it; the torch gather moves it); the library renders into it
         image = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -377,7 +379,9 @@ def main():
                     gather_list = [torch.zeros_like(pack) for _ in range(world)]
 
         def gather():
-            if args.gather == "capi":
+            if args.gather == "capi" and args.realtime:
+                ctx.group_gather_async(0)  # queued behind an event on a second stream: the next frame is traced meanwhile
+            elif args.gather == "capi":
                 ctx.group_gather(0)
             elif rehearsal:  # gloo gathers host tensors
                 host = image.cpu()
@@ -439,6 +443,8 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(args.warmup + k)
+        if world > 1 and args.gather == "capi" and args.realtime:
+            ctx.group_wait()  # the last frame's rows have landed
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -449,12 +455,14 @@ def main():
 
     elapsed, st, image, ctx = timed_leg(pt.PT_CFG_PROFILE_STAGES | args.cfg_flags)
     value = paths_per_step * args.steps / elapsed / 1e6
-    nan_frac = float(torch.isnan(image[..., :3]).any(dim=-1).float().mean().item()) if rank == 0 else 0.0
-    image_hash = None
+    nan_frac, image_hash = 0.0, None
     if rank == 0:  # the image is a pure function of scene, seed, size and spp (never of GPU count, tiling or pass form)
         import hashlib
 
-        image_hash = hashlib.sha1(image.cpu().numpy().tobytes()).hexdigest()[:16]
+        # (after asynchronous gathers the assembled frame lives in the library: pt_readback returns it)
+        final = torch.from_numpy(ctx.readback()) if (world > 1 and args.gather == "capi" and args.realtime) else image.cpu()
+        nan_frac = float(torch.isnan(final[..., :3]).any(dim=-1).float().mean().item())
+        image_hash = hashlib.sha1(final.numpy().tobytes()).hexdigest()[:16]
     ctx.close()
     del image
 

@@ -376,6 +376,25 @@ int64_t pt_group_staged_row(uint32_t height, int world, int root, uint32_t y);
  * its rows of the same width x height image. Synchronous; on return the root's image holds every row. */
 int pt_group_gather(pt_ctx *ctx, int root);
 int pt_group_gather_local(pt_ctx *const *ctxs, int n, int root);
+/* The gather of a frame loop, without a host synchronisation (replaces the main loop reading the shared buffer while
+ * the workers already write the next frame, src/lib.rs:476-509). Every member calls it after pt_render; it returns as
+ * soon as the work is queued. On the render stream the member's rows are packed into one of two staging buffers (a
+ * few microseconds); from then on the member may trace its next frame into its image. The transfers run on a second
+ * stream behind an event, and the root assembles the whole frame (its own rows and everyone else's) in one of two
+ * frame buffers of its own, so that frame k's rows land while frame k + 1 is traced and no frame is ever seen half
+ * new. After the call, on the root, pt_readback, pt_tonemap_device, pt_display_transform and pt_present_submit read
+ * the LATEST ASSEMBLED FRAME instead of the context's own image (their stream waits for that frame's transfers, the
+ * host does not); pt_group_gather, pt_image_bind, a change of image size and pt_group_leave put them back on the
+ * context's own image. pt_group_wait blocks the host until this member's part of the last asynchronous gather is
+ * complete (end of a loop, before timing stops). A lone context may call it too (a group of one). Every member must
+ * issue its gathers in the same order; pt_group_gather first drains the asynchronous ones. */
+int pt_group_gather_async(pt_ctx *ctx, int root);
+int pt_group_wait(pt_ctx *ctx);
+/* The asynchronous gather's data path on ONE GPU (group of one): as pt_group_gather_async for a virtual group of two in
+ * which rows 0, 2, 4, ... are the root's own and rows 1, 3, 5, ... travel from the context to itself through RCCL on
+ * the second stream. The assembled frame must equal the image that was traced (the caller compares, frame by frame,
+ * while it already traces the next one). */
+int pt_group_loopback_async(pt_ctx *ctx);
 int pt_group_leave(pt_ctx *ctx);                                           /* also done by pt_destroy */
 /* Checks the gather's data path on ONE GPU (group of one): the image's odd rows are packed, wiped, sent from the
  * context to itself through RCCL and scattered back; the image must come out unchanged. */

@@ -246,7 +246,8 @@ EXPORTS = [
     "pt_abi_version", "pt_intersect_static", "pt_asset_register_image", "pt_group_unique_id", "pt_group_join",
     "pt_group_join_local", "pt_group_rows", "pt_group_gather", "pt_group_gather_local", "pt_group_leave",
     "pt_group_loopback", "pt_render_jobs", "pt_present_attach", "pt_present_slot", "pt_present_pinned", "pt_present_submit", "pt_present_wait", "pt_present_detach",
-    "pt_device_alloc_count", "pt_group_layout", "pt_group_staged_row",
+    "pt_device_alloc_count", "pt_group_layout", "pt_group_staged_row", "pt_group_gather_async", "pt_group_wait",
+    "pt_group_loopback_async",
 ]
 
 _vp = C.c_void_p
@@ -324,6 +325,9 @@ _sig("pt_device_alloc_count", C.c_uint64)
 _sig("pt_group_gather", C.c_int, _vp, C.c_int)
 _sig("pt_group_gather_local", C.c_int, C.POINTER(_vp), C.c_int, C.c_int)
 _sig("pt_group_leave", C.c_int, _vp)
+_sig("pt_group_gather_async", C.c_int, _vp, C.c_int)
+_sig("pt_group_wait", C.c_int, _vp)
+_sig("pt_group_loopback_async", C.c_int, _vp)
 _sig("pt_group_loopback", C.c_int, _vp)
 _sig("pt_present_attach", C.c_int, _vp, _vp, C.c_size_t, C.c_uint32)
 _sig("pt_present_slot", _vp, _vp, C.c_uint32)
@@ -617,6 +621,16 @@ class Context:
 
     def group_gather(self, root=0):
         self._check(lib.pt_group_gather(self._h, root), "pt_group_gather")
+
+    def group_gather_async(self, root=0):
+        """Queues the gather of the frame just traced and returns; the root's readers then see the assembled frame."""
+        self._check(lib.pt_group_gather_async(self._h, root), "pt_group_gather_async")
+
+    def group_wait(self):
+        self._check(lib.pt_group_wait(self._h), "pt_group_wait")
+
+    def group_loopback_async(self):
+        self._check(lib.pt_group_loopback_async(self._h), "pt_group_loopback_async")
 
     def group_leave(self):
         self._check(lib.pt_group_leave(self._h), "pt_group_leave")

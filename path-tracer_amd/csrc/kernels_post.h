@@ -173,6 +173,15 @@ __global__ __launch_bounds__(kBlock) void k_pack_rows(const float4 *image, uint3
         packed[i] = image[(uint64_t)group_image_row(step, phase, k) * width + x];
     }
 }
+// The inverse of k_pack_rows for one member: image row phase + k step = row k of `packed`.
+__global__ __launch_bounds__(kBlock) void k_unpack_member_rows(float4 *image, uint32_t width, uint32_t height, uint32_t step,
+                                                               uint32_t phase, const float4 *packed) {
+    const uint64_t n = (uint64_t)group_rows_of(height, step, phase) * width;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t k = (uint32_t)(i / width), x = (uint32_t)(i % width);
+        image[(uint64_t)group_image_row(step, phase, k) * width + x] = packed[i];
+    }
+}
 // Every member's packed rows except `skip`'s own (they are in the image already) lie one behind the other in
 // `packed`, in rank order; scatters them all into the image.
 __global__ __launch_bounds__(kBlock) void k_unpack_rows(float4 *image, uint32_t width, uint32_t height, uint32_t step,

@@ -204,6 +204,21 @@ struct pt_ctx {
     ncclComm_t comm = nullptr;
     int group_rank = 0, group_world = 1;
 
+    // asynchronous gather (pt_group_gather_async): a second stream carries the transfers while the render stream traces
+    // the next frame. Slot = gather number & 1.
+    hipStream_t comm_stream = nullptr;
+    void *d_gpack[2] = {nullptr, nullptr};      // this member's packed rows of the frame being gathered
+    void *d_grecv[2] = {nullptr, nullptr};      // root: the other members' packed rows
+    void *d_gathered[2] = {nullptr, nullptr};   // root: the assembled frames
+    size_t gpack_bytes = 0, grecv_bytes = 0, gathered_bytes = 0;
+    hipEvent_t ev_packed[2] = {nullptr, nullptr};   // render stream: the slot's rows are packed
+    hipEvent_t ev_gathered[2] = {nullptr, nullptr}; // comm stream: the slot's gather is complete (staging free, frame assembled)
+    hipEvent_t ev_consumed = nullptr;               // render stream: the last reader of an assembled frame is done
+    bool consumed_pending = false;
+    bool gather_used[2] = {false, false};
+    uint64_t gather_seq = 0;
+    int gathered_slot = -1; // root: the assembled frame pt_readback / pt_tonemap_device / pt_display_transform / pt_present_submit read; -1: the context's own image
+
     // presentation ring (pt_present_*): the host's staging memory, pinned, and one device snapshot per slot
     static constexpr uint32_t kPresentSlots = 4;
     unsigned char *present_host = nullptr;
@@ -305,6 +320,7 @@ int ensure_image(pt_ctx *ctx, uint32_t w, uint32_t h) {
         ctx->d_image = ctx->d_image_owned;
         ctx->width = w;
         ctx->height = h;
+        ctx->gathered_slot = -1; // an assembled frame of the old size is not this image
         if (ctx->d_frames) (void)hipFree(ctx->d_frames);
         ctx->d_frames = nullptr;
     }
@@ -354,6 +370,25 @@ bool device_range_ok(int device, const void *p, size_t bytes) {
     }
     const char *b = (const char *)base, *q = (const char *)p;
     return q >= b && bytes <= size && (size_t)(q - b) <= size - bytes;
+}
+
+// The image the reading entry points (pt_readback, pt_tonemap_device, pt_display_transform, pt_present_submit) take:
+// the context's own, or on a group's root after pt_group_gather_async the latest assembled frame, which the render
+// stream first waits for. shown_done marks the end of such a read, so that the slot is not reassembled under it.
+int shown_image(pt_ctx *ctx, const float **image) {
+    *image = ctx->d_image;
+    if (ctx->gathered_slot >= 0) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[ctx->gathered_slot], 0));
+        *image = (const float *)ctx->d_gathered[ctx->gathered_slot];
+    }
+    return PT_OK;
+}
+int shown_done(pt_ctx *ctx) {
+    if (ctx->gathered_slot >= 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_consumed, ctx->stream));
+        ctx->consumed_pending = true;
+    }
+    return PT_OK;
 }
 
 D3 hd3(const double p[3]) { return D3{p[0], p[1], p[2]}; }
@@ -805,6 +840,7 @@ void apply_tuning_overrides(pt_tuning &t) {
 // ================================================================================================================
 extern "C" {
 static int quantise_nodes(pt_ctx *ctx);
+static void gather_async_release(pt_ctx *ctx);
 
 int pt_create(const pt_config *cfg, pt_ctx **out) {
     // the structure of ABI version 1 ended before `tuning`: still accepted, with the defaults
@@ -852,6 +888,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    gather_async_release(ctx);
     if (ctx->comm && rccl_api()) (void)rccl_api()->CommDestroy(ctx->comm);
     (void)pt_present_detach(ctx);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
@@ -1098,6 +1135,7 @@ int pt_image_bind(pt_ctx *ctx, void *device_rgba, uint32_t width, uint32_t heigh
     if (ctx->d_image_owned) (void)hipFree(ctx->d_image_owned);
     ctx->d_image_owned = nullptr;
     ctx->image_external = true;
+    ctx->gathered_slot = -1;
     ctx->d_image = (float *)device_rgba;
     ctx->width = width;
     ctx->height = height;
@@ -1222,7 +1260,10 @@ int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats) {
     if (!ctx->d_image) return set_error(ctx, PT_ERR_INVALID_ARG, "no image has been rendered");
     if (n_floats != (size_t)ctx->width * ctx->height * 4) return set_error(ctx, PT_ERR_INVALID_ARG, "readback size mismatch");
     (void)hipSetDevice(ctx->device);
-    HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->d_image, n_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    const float *image;
+    if (int rc = shown_image(ctx, &image); rc != PT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(rgba, image, n_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = shown_done(ctx); rc != PT_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -1345,8 +1386,11 @@ int pt_tonemap_device(pt_ctx *ctx, uint8_t *rgb8_out, size_t n_bytes) {
     const int rc = ensure_stage(ctx, 1, need);
     if (rc != PT_OK) return rc;
     const uint32_t n = ctx->width * ctx->height;
-    hipLaunchKernelGGL(k_tonemap_rgb8, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image, ctx->width,
+    const float *image;
+    if (int rc2 = shown_image(ctx, &image); rc2 != PT_OK) return rc2;
+    hipLaunchKernelGGL(k_tonemap_rgb8, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image, ctx->width,
                        ctx->height, (uint8_t *)ctx->d_stage[1]);
+    if (int rc2 = shown_done(ctx); rc2 != PT_OK) return rc2;
     HIP_TRY(ctx, hipMemcpyAsync(rgb8_out, ctx->d_stage[1], need, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -1361,8 +1405,11 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     const int rc = ensure_stage(ctx, 1, need * sizeof(float));
     if (rc != PT_OK) return rc;
     const uint32_t n = ctx->width * ctx->height;
-    hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image,
+    const float *image;
+    if (int rc2 = shown_image(ctx, &image); rc2 != PT_OK) return rc2;
+    hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image,
                        ctx->width, ctx->height, exposure, (float *)ctx->d_stage[1]);
+    if (int rc2 = shown_done(ctx); rc2 != PT_OK) return rc2;
     HIP_TRY(ctx, hipMemcpyAsync(rgba_out, ctx->d_stage[1], need * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -1445,14 +1492,17 @@ int pt_present_submit(pt_ctx *ctx, uint32_t slot, int kind, float exposure) {
         HIP_TRY(ctx, counted_malloc(&ctx->d_present[slot], need));
         ctx->present_bytes[slot] = need;
     }
+    const float *image;
+    if (int rc = shown_image(ctx, &image); rc != PT_OK) return rc;
     if (kind == PT_PRESENT_RAW) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_present[slot], ctx->d_image, need, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_present[slot], image, need, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         const uint32_t n = ctx->width * ctx->height;
-        hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->d_image,
+        hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image,
                            ctx->width, ctx->height, exposure, (float *)ctx->d_present[slot]);
         HIP_TRY(ctx, hipGetLastError());
     }
+    if (int rc = shown_done(ctx); rc != PT_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_snapshot[slot], ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->present_stream, ctx->ev_snapshot[slot], 0));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->present_host + (size_t)slot * ctx->present_slot_bytes, ctx->d_present[slot], need,
@@ -1711,6 +1761,11 @@ static int group_gather(pt_ctx *const *m, int n_local, int root) {
             return set_error(c, PT_ERR_INVALID_ARG, "every member must hold an image of the same size: render first");
         if (c->group_world != world) return set_error(c, PT_ERR_INVALID_ARG, "members of different groups");
     }
+    for (int k = 0; k < n_local; ++k) {
+        m[k]->gathered_slot = -1; // the rows land in the root's own image
+        // transfers of earlier asynchronous gathers on the same communicator come first
+        if (m[k]->comm_stream) HIP_TRY(m[k], hipStreamSynchronize(m[k]->comm_stream));
+    }
     if (world == 1) return PT_OK;
     RCCL_OR_FAIL(first);
     const size_t row_bytes = (size_t)w * 4 * sizeof(float);
@@ -1846,8 +1901,153 @@ int pt_group_gather_local(pt_ctx *const *ctxs, int n, int root) {
     return group_gather(ctxs, n, root);
 }
 
+// The asynchronous gather of one member. `loopback`: a virtual group of two on one context (rows 0, 2, ... are the
+// root's own, rows 1, 3, ... travel from the context to itself through RCCL), which is what one GPU can check.
+static int gather_async(pt_ctx *ctx, int root, bool loopback) {
+    const int world = loopback ? 2 : ctx->group_world, rank = loopback ? 0 : ctx->group_rank;
+    if (loopback) root = 0;
+    if (root < 0 || root >= world) return set_error(ctx, PT_ERR_INVALID_ARG, "root outside the group");
+    if (!ctx->comm && (world > 1 || loopback)) return set_error(ctx, PT_ERR_INVALID_ARG, "context is not in a group");
+    if (!ctx->d_image || ctx->width == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "no image: render first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const RcclApi *nccl = (world > 1) ? rccl_api() : nullptr;
+    if (world > 1 && !nccl) return set_error(ctx, PT_ERR_COMM, "librccl.so.1 could not be loaded");
+    const uint32_t w = ctx->width, h = ctx->height;
+    const size_t row_bytes = (size_t)w * 4 * sizeof(float);
+    const bool is_root = rank == root;
+    // streams, events and buffers: made once, remade when the image size changes (both streams drained first)
+    if (!ctx->comm_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_packed[k], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_gathered[k], hipEventDisableTiming));
+        }
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_consumed, hipEventDisableTiming));
+    }
+    const size_t own_rows = loopback ? h : rows_of_member(h, (uint32_t)world, (uint32_t)rank); // loopback packs both halves
+    const size_t need_pack = std::max<size_t>(own_rows * row_bytes, 16);
+    const size_t need_recv = is_root ? std::max<size_t>(((size_t)h - rows_of_member(h, (uint32_t)world, (uint32_t)root)) * row_bytes, 16) : 0;
+    const size_t need_frame = is_root ? (size_t)h * row_bytes : 0;
+    if (need_pack > ctx->gpack_bytes || need_recv > ctx->grecv_bytes || need_frame != ctx->gathered_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+        for (int k = 0; k < 2; ++k) {
+            for (void **p : {&ctx->d_gpack[k], &ctx->d_grecv[k], &ctx->d_gathered[k]}) {
+                if (*p) (void)hipFree(*p);
+                *p = nullptr;
+            }
+            HIP_TRY(ctx, counted_malloc(&ctx->d_gpack[k], need_pack));
+            if (need_recv) HIP_TRY(ctx, counted_malloc(&ctx->d_grecv[k], need_recv));
+            if (need_frame) HIP_TRY(ctx, counted_malloc(&ctx->d_gathered[k], need_frame));
+            ctx->gather_used[k] = false;
+        }
+        ctx->gpack_bytes = need_pack;
+        ctx->grecv_bytes = need_recv;
+        ctx->gathered_bytes = need_frame;
+        ctx->gathered_slot = -1;
+        ctx->consumed_pending = false;
+    }
+    const int s = (int)(ctx->gather_seq & 1u);
+    hipStream_t R = ctx->stream, C = ctx->comm_stream;
+    // render stream: once the slot's previous gather has let go of the staging buffer, pack this member's rows of the frame
+    // just traced. From here on the image may be traced into again.
+    if (ctx->gather_used[s]) HIP_TRY(ctx, hipStreamWaitEvent(R, ctx->ev_gathered[s], 0));
+    float4 *pack = (float4 *)ctx->d_gpack[s];
+    const uint32_t own = rows_of_member(h, (uint32_t)world, (uint32_t)rank);
+    if (own)
+        hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(ctx, (uint64_t)own * w)), dim3(kBlock), 0, R, (const float4 *)ctx->d_image, w, h,
+                           (uint32_t)world, (uint32_t)rank, pack);
+    float4 *pack_peer = pack + (size_t)own * w; // loopback: the rows of the virtual second member, behind the root's
+    const uint32_t peer_rows = loopback ? rows_of_member(h, 2u, 1u) : 0u;
+    if (peer_rows)
+        hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(ctx, (uint64_t)peer_rows * w)), dim3(kBlock), 0, R, (const float4 *)ctx->d_image, w, h,
+                           2u, 1u, pack_peer);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_packed[s], R));
+    // comm stream: the transfers, and on the root the assembly of the frame, beside whatever the render stream does next
+    HIP_TRY(ctx, hipStreamWaitEvent(C, ctx->ev_packed[s], 0));
+    if (is_root && ctx->consumed_pending) HIP_TRY(ctx, hipStreamWaitEvent(C, ctx->ev_consumed, 0)); // a reader of this slot's old frame
+    if (world > 1) {
+        NCCL_TRY(ctx, nccl->GroupStart());
+        if (is_root) {
+            for (int r = 0; r < world; ++r) {
+                if (r == root) continue;
+                const size_t count = (size_t)rows_of_member(h, (uint32_t)world, (uint32_t)r) * w * 4;
+                const size_t offset = (size_t)group_rows_before(h, (uint32_t)world, (uint32_t)root, (uint32_t)r) * w * 4;
+                if (count) NCCL_TRY_IN_GROUP(ctx, nccl->Recv((float *)ctx->d_grecv[s] + offset, count, ncclFloat, loopback ? 0 : r, ctx->comm, C));
+            }
+        }
+        if (!is_root || loopback) {
+            const size_t count = (size_t)(loopback ? peer_rows : own) * w * 4;
+            if (count) NCCL_TRY_IN_GROUP(ctx, nccl->Send(loopback ? (const void *)pack_peer : (const void *)pack, count, ncclFloat, loopback ? 0 : root, ctx->comm, C));
+        }
+        NCCL_TRY(ctx, nccl->GroupEnd());
+    }
+    if (is_root) {
+        float4 *frame = (float4 *)ctx->d_gathered[s];
+        if (own)
+            hipLaunchKernelGGL(k_unpack_member_rows, dim3(grid_for(ctx, (uint64_t)own * w)), dim3(kBlock), 0, C, frame, w, h, (uint32_t)world,
+                               (uint32_t)root, (const float4 *)pack);
+        if (world > 1)
+            hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(ctx, (uint64_t)w * h)), dim3(kBlock), 0, C, frame, w, h, (uint32_t)world,
+                               (uint32_t)root, (const float4 *)ctx->d_grecv[s]);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_gathered[s], C));
+    ctx->gather_used[s] = true;
+    ctx->gather_seq += 1;
+    if (is_root) ctx->gathered_slot = s;
+    return PT_OK;
+}
+
+int pt_group_gather_async(pt_ctx *ctx, int root) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    return gather_async(ctx, root, false);
+}
+
+int pt_group_loopback_async(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!ctx->comm || ctx->group_world != 1) return set_error(ctx, PT_ERR_INVALID_ARG, "needs a group of one");
+    return gather_async(ctx, 0, true);
+}
+
+int pt_group_wait(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (ctx->gather_seq == 0) return PT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_gathered[(ctx->gather_seq - 1) & 1u]));
+    return PT_OK;
+}
+
+// Ends the asynchronous gathers of a context: both streams drained, the readers back on the context's own image.
+static void gather_async_release(pt_ctx *ctx) {
+    if (!ctx->comm_stream) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    for (int k = 0; k < 2; ++k) {
+        for (void **p : {&ctx->d_gpack[k], &ctx->d_grecv[k], &ctx->d_gathered[k]}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        if (ctx->ev_packed[k]) (void)hipEventDestroy(ctx->ev_packed[k]);
+        if (ctx->ev_gathered[k]) (void)hipEventDestroy(ctx->ev_gathered[k]);
+        ctx->ev_packed[k] = ctx->ev_gathered[k] = nullptr;
+        ctx->gather_used[k] = false;
+    }
+    if (ctx->ev_consumed) (void)hipEventDestroy(ctx->ev_consumed);
+    ctx->ev_consumed = nullptr;
+    (void)hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr;
+    ctx->gpack_bytes = ctx->grecv_bytes = ctx->gathered_bytes = 0;
+    ctx->gather_seq = 0;
+    ctx->gathered_slot = -1;
+    ctx->consumed_pending = false;
+}
+
 int pt_group_leave(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    gather_async_release(ctx);
     if (ctx->comm) {
         RCCL_OR_FAIL(ctx);
         (void)hipSetDevice(ctx->device);

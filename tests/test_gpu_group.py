@@ -71,6 +71,56 @@ def test_interleaved_rows_of_a_virtual_group_compose():
     ctx.close()
 
 
+@pytest.mark.parametrize("form", ["loopback", "lone"])
+@pytest.mark.parametrize("w,h", [(96, 64), (33, 7)])
+def test_asynchronous_gather_frame_sequence(form, w, h):
+    """pt_group_gather_async in a realtime frame loop on one GPU: frame k is queued for gathering and frame k + 1 is
+    traced at once, with no host synchronisation in between; the frame the root's readers then see must be frame k, bit
+    for bit, not a mixture. `loopback`: a virtual group of two (odd rows travel from the context to itself through RCCL
+    on the second stream); `lone`: a context alone (a group of one: its own rows are packed and assembled, nothing is
+    sent). The reference sequence comes from a second context that reads every frame back before it traces the next."""
+    scene = ptgpu.Scene.named("cornell_box", w / h)
+    frames = 6
+    ref_ctx = ptgpu.Context(device=0, seed=21, max_paths_in_flight=1 << 16)
+    ref_ctx.upload(scene)
+    want = []
+    for k in range(frames):
+        ref_ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=k)
+        want.append(ref_ctx.readback().copy())
+    ref_ctx.close()
+    assert not np.array_equal(want[0], want[1])  # progressive frames differ, so a stale or mixed frame would show
+
+    ctx = ptgpu.Context(device=0, seed=21, max_paths_in_flight=1 << 16)
+    ctx.upload(scene)
+    if form == "loopback":
+        ctx.group_join(ptgpu.group_unique_id(), 0, 1)
+        gather = ctx.group_loopback_async
+    else:
+        gather = ctx.group_gather_async
+    got = []
+    ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=0)
+    for k in range(frames):
+        gather()                                                       # frame k: queued, not waited for
+        if k + 1 < frames:
+            ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=k + 1)  # traced while frame k's rows travel
+        got.append(ctx.readback().copy())                              # the assembled frame k (the image holds k + 1 by now)
+    ctx.group_wait()
+    for k in range(frames):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), f"frame {k}"
+    # the display transform and the presentation ring read the assembled frame too
+    ring = ctx.present_attach(None, slots=2, width=w, height=h)
+    ctx.present_submit(0)
+    ctx.present_wait(0)
+    assert np.array_equal(ring[0].view(np.uint32), want[-1].view(np.uint32))
+    ctx.present_detach()
+    # the synchronous gather puts the readers back on the context's own image
+    ctx.group_gather(0)
+    assert np.array_equal(ctx.readback().view(np.uint32), want[-1].view(np.uint32))
+    if form == "loopback":
+        ctx.group_leave()
+    ctx.close()
+
+
 def test_bench_multi_rank_rehearsal():
     """bench.py --gpus 2 on a one-GPU box: both ranks on GPU 0 over gloo (PTGPU_BENCH_REHEARSAL=1; RCCL takes one rank
     per device, so the gather goes through the host). The launcher path, the row split, the gather and the line's
