@@ -167,10 +167,11 @@ def parse_args(argv=None):
     ap.add_argument("--realtime", action="store_true",
                     help="progressive frames instead of the offline render (src/lib.rs:118-123: spp 1, depth 10, "
                          "80 %% pixel skip, running mean); pass --width 1920 --height 1080 --steps <frames>")
-    ap.add_argument("--present", choices=["none", "readback", "ring"], default="none",
+    ap.add_argument("--present", choices=["none", "readback", "ring", "ring8"], default="none",
                     help="--realtime on one GPU: every frame also goes to host memory, as the reference hands its buffer to "
                          "the presentation graph (src/lib.rs:496-509): 'readback' = pt_readback after each frame, 'ring' = "
-                         "pt_present_submit into a two-slot ring, waiting for a frame only when the next one has been traced")
+                         "pt_present_submit into a two-slot ring, waiting for a frame only when the next one has been traced; "
+                         "'ring8' = the same with PT_PRESENT_DISPLAY8 (the display transform as 8-bit RGBA: a quarter of the bytes)")
     ap.add_argument("--gather", choices=["capi", "torch"], default="capi",
                     help="N > 1: rows to rank 0 through pt_group_gather (RCCL inside the library) or torch.distributed.gather")
     args = ap.parse_args(argv)
@@ -391,8 +392,9 @@ def main():
                 tiles.gather_rows(image, rank, world, dist, pack=pack, gather_list=gather_list)
 
         ring = None
-        if args.present == "ring" and world == 1:
+        if args.present in ("ring", "ring8") and world == 1:
             ring = ctx.present_attach(None, slots=2, width=W, height=H)  # the library's page-locked ring
+        present_kind = pt.PT_PRESENT_DISPLAY8 if args.present == "ring8" else pt.PT_PRESENT_RAW
 
         def step(frame):
             ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, flags=rflags, rows=rows)
@@ -401,7 +403,7 @@ def main():
             elif args.present == "readback":
                 ctx.readback()
             elif ring is not None:
-                ctx.present_submit(frame & 1)
+                ctx.present_submit(frame & 1, kind=present_kind)
                 ctx.present_wait((frame & 1) ^ 1)  # the frame before this one is shown now
 
         def barrier():

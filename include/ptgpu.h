@@ -513,7 +513,12 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
  * the previous one crosses PCIe. pt_present_wait blocks until a slot's bytes are in host memory (a slot never
  * submitted is ready at once); submitting to a slot waits for that slot's previous copy first. The first submit of a
  * slot (and the first after the image grew) allocates its device snapshot. pt_destroy detaches. */
-enum pt_present_kind { PT_PRESENT_RAW = 0, PT_PRESENT_DISPLAY = 1 };
+/* PT_PRESENT_DISPLAY8 / PT_PRESENT_DISPLAY8_SRGB: the display transform as the 8-bit swapchain image keeps it, the
+ * frame the reference's tonemap pass leaves in its surface (assets/shaders/tonemap.frag:55-70 drawn into the format of
+ * get_surface_format, src/lib.rs:257): one 32-bit word per pixel, R in the low byte, alpha 255, each channel the nearest
+ * of 256 levels of the value in [0, 1] (floor(255 v + 0.5)), for the _SRGB kind after the sRGB transfer function that an
+ * *_SRGB surface applies on write. A quarter of the bytes of the f32 kinds across PCIe: width * height * 4 per slot. */
+enum pt_present_kind { PT_PRESENT_RAW = 0, PT_PRESENT_DISPLAY = 1, PT_PRESENT_DISPLAY8 = 2, PT_PRESENT_DISPLAY8_SRGB = 3 };
 int pt_present_attach(pt_ctx *ctx, void *host_staging, size_t slot_bytes, uint32_t n_slots);
 void *pt_present_slot(pt_ctx *ctx, uint32_t slot);   /* host address of a slot; NULL if there is none */
 int pt_present_pinned(pt_ctx *ctx);                  /* 1 if the attached ring is page-locked, else 0 */

@@ -335,7 +335,7 @@ _sig("pt_present_pinned", C.c_int, _vp)
 _sig("pt_present_submit", C.c_int, _vp, C.c_uint32, C.c_int, C.c_float)
 _sig("pt_present_wait", C.c_int, _vp, C.c_uint32)
 _sig("pt_present_detach", C.c_int, _vp)
-PT_PRESENT_RAW, PT_PRESENT_DISPLAY = 0, 1
+PT_PRESENT_RAW, PT_PRESENT_DISPLAY, PT_PRESENT_DISPLAY8, PT_PRESENT_DISPLAY8_SRGB = 0, 1, 2, 3
 _sig("pt_abi_version", C.c_uint32)
 _sig("pt_intersect_static", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
 PT_INTERSECT_STATIC_MAX_RAYS = 65536
@@ -667,6 +667,12 @@ class Context:
         ring = np.ctypeslib.as_array((C.c_float * (slots * height * width * 4)).from_address(base)).reshape(slots, height, width, 4)
         self._present_staging = ring  # a view of the library's memory: invalid after present_detach / close
         return ring
+
+    def present_slot_rgba8(self, slot, width=None, height=None):
+        """A slot of the ring viewed as the (height, width, 4) uint8 frame the 8-bit present kinds write."""
+        width, height = width or self.width, height or self.height
+        base = lib.pt_present_slot(self._h, slot)
+        return np.ctypeslib.as_array((C.c_uint8 * (height * width * 4)).from_address(base)).reshape(height, width, 4)
 
     def present_pinned(self):
         return bool(lib.pt_present_pinned(self._h))

@@ -88,8 +88,15 @@ __device__ __forceinline__ float aces_fit(float v) { // RRTAndODTFit, tonemap.fr
     const float b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
     return a / b;
 }
+// What an 8-bit swapchain image keeps of a colour channel in [0, 1]: the nearest of 256 levels (UNORM), after the sRGB
+// transfer function when the surface format is an *_SRGB one (the output stage applies it; the shader writes linear values,
+// its gamma line is commented out: tonemap.frag:68-69).
+__device__ __forceinline__ uint32_t unorm8(float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); }
+__device__ __forceinline__ float srgb_oetf(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
+// OUT: 0 = f32 RGBA, 1 = RGBA8 UNORM, 2 = RGBA8 with the sRGB transfer function (one 32-bit word per pixel, R in the low byte)
+template <int OUT>
 __global__ __launch_bounds__(kBlock) void k_display_transform(const float *image, uint32_t width, uint32_t height,
-                                                              float exposure, float *out) {
+                                                              float exposure, void *out_v) {
     const uint32_t n = width * height;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
         const uint32_t i = p % width, j = p / width; // j = 0 is the top of the screen
@@ -109,11 +116,18 @@ __global__ __launch_bounds__(kBlock) void k_display_transform(const float *image
         const float u = ((float)i + 0.5f) / (float)width, v = 1.0f - ((float)j + 0.5f) / (float)height;
         const float du = u - 0.5f, dv = v - 0.5f;
         const float vignette = 1.0f - sqrtf(du * du + dv * dv);
-        float *o = out + (size_t)p * 4;
-        o[0] = orr * vignette;
-        o[1] = org * vignette;
-        o[2] = orb * vignette;
-        o[3] = 1.0f;
+        const float cr = orr * vignette, cg = org * vignette, cb = orb * vignette;
+        if constexpr (OUT == 0) {
+            float *o = (float *)out_v + (size_t)p * 4;
+            o[0] = cr;
+            o[1] = cg;
+            o[2] = cb;
+            o[3] = 1.0f;
+        } else if constexpr (OUT == 1) {
+            ((uint32_t *)out_v)[p] = unorm8(cr) | (unorm8(cg) << 8) | (unorm8(cb) << 16) | 0xff000000u;
+        } else {
+            ((uint32_t *)out_v)[p] = unorm8(srgb_oetf(cr)) | (unorm8(srgb_oetf(cg)) << 8) | (unorm8(srgb_oetf(cb)) << 16) | 0xff000000u;
+        }
     }
 }
 

@@ -1407,8 +1407,8 @@ int pt_display_transform(pt_ctx *ctx, float exposure, float *rgba_out, size_t n_
     const uint32_t n = ctx->width * ctx->height;
     const float *image;
     if (int rc2 = shown_image(ctx, &image); rc2 != PT_OK) return rc2;
-    hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image,
-                       ctx->width, ctx->height, exposure, (float *)ctx->d_stage[1]);
+    hipLaunchKernelGGL(k_display_transform<0>, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image,
+                       ctx->width, ctx->height, exposure, ctx->d_stage[1]);
     if (int rc2 = shown_done(ctx); rc2 != PT_OK) return rc2;
     HIP_TRY(ctx, hipMemcpyAsync(rgba_out, ctx->d_stage[1], need * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1478,9 +1478,10 @@ int pt_present_wait(pt_ctx *ctx, uint32_t slot) {
 int pt_present_submit(pt_ctx *ctx, uint32_t slot, int kind, float exposure) {
     if (!ctx) return PT_ERR_INVALID_ARG;
     if (!ctx->present_host || slot >= ctx->present_slots) return set_error(ctx, PT_ERR_INVALID_ARG, "no such presentation slot");
-    if (kind != PT_PRESENT_RAW && kind != PT_PRESENT_DISPLAY) return set_error(ctx, PT_ERR_INVALID_ARG, "unknown pt_present_kind");
+    if (kind < PT_PRESENT_RAW || kind > PT_PRESENT_DISPLAY8_SRGB) return set_error(ctx, PT_ERR_INVALID_ARG, "unknown pt_present_kind");
     if (!ctx->d_image || ctx->width == 0) return set_error(ctx, PT_ERR_INVALID_ARG, "no image: render first");
-    const size_t need = (size_t)ctx->width * ctx->height * 4 * sizeof(float);
+    const bool eight = kind == PT_PRESENT_DISPLAY8 || kind == PT_PRESENT_DISPLAY8_SRGB;
+    const size_t need = (size_t)ctx->width * ctx->height * 4 * (eight ? sizeof(uint8_t) : sizeof(float));
     if (need > ctx->present_slot_bytes) return set_error(ctx, PT_ERR_TOO_LARGE, "the image does not fit a presentation slot");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the slot's previous frame must have left its snapshot before the snapshot is overwritten
@@ -1498,8 +1499,13 @@ int pt_present_submit(pt_ctx *ctx, uint32_t slot, int kind, float exposure) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_present[slot], image, need, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         const uint32_t n = ctx->width * ctx->height;
-        hipLaunchKernelGGL(k_display_transform, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image,
-                           ctx->width, ctx->height, exposure, (float *)ctx->d_present[slot]);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, image, ctx->width, ctx->height, exposure,
+                               ctx->d_present[slot]);
+        };
+        if (kind == PT_PRESENT_DISPLAY) launch(k_display_transform<0>);
+        else if (kind == PT_PRESENT_DISPLAY8) launch(k_display_transform<1>);
+        else launch(k_display_transform<2>);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (int rc = shown_done(ctx); rc != PT_OK) return rc;

@@ -93,3 +93,36 @@ def test_argument_errors():
             ctx.present_attach(np.zeros((5, 8, 8, 4), dtype=np.float32))  # more than four slots
     finally:
         ctx.close()
+
+
+def test_eight_bit_kinds_are_the_display_transform_quantised():
+    """PT_PRESENT_DISPLAY8: every byte is floor(255 v + 0.5) of pt_display_transform's f32 value, alpha 255, a quarter of
+    the bytes (a slot of width x height x 4 bytes suffices). PT_PRESENT_DISPLAY8_SRGB: the same after the sRGB transfer
+    function; its power function is evaluated in f32 on both sides, so a byte may differ by one level where the two
+    roundings of the power straddle a level boundary (bar: at most one level, on at most 0.1 % of the bytes)."""
+    _, ctx = _fresh()
+    try:
+        ctx.render(W, H, spp=8, max_depth=50)
+        ctx.present_attach(None, slots=2, width=W // 2, height=H // 2)  # a quarter of an f32 frame per slot
+        with pytest.raises(ptgpu.PtError) as e:
+            ctx.present_submit(0, kind=ptgpu.PT_PRESENT_DISPLAY)  # the f32 kinds do not fit such a slot
+        assert e.value.code == ptgpu.PT_ERR_TOO_LARGE
+        want = ctx.display_transform(1.3).astype(np.float32)
+        ctx.present_submit(0, kind=ptgpu.PT_PRESENT_DISPLAY8, exposure=1.3)
+        ctx.present_submit(1, kind=ptgpu.PT_PRESENT_DISPLAY8_SRGB, exposure=1.3)
+        ctx.present_wait(0)
+        ctx.present_wait(1)
+        got = ctx.present_slot_rgba8(0, W, H).copy()
+        quantised = np.floor(np.clip(want, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+        assert np.array_equal(got, quantised)
+        assert (got[..., 3] == 255).all() and got[..., :3].max() > 100
+        srgb = ctx.present_slot_rgba8(1, W, H).copy()
+        c = np.clip(want[..., :3], 0.0, 1.0).astype(np.float32)
+        curve = np.where(c <= np.float32(0.0031308), np.float32(12.92) * c,
+                         np.float32(1.055) * np.power(c, np.float32(1.0 / 2.4), dtype=np.float32) - np.float32(0.055))
+        want8 = np.floor(np.clip(curve, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.int32)
+        diff = np.abs(srgb[..., :3].astype(np.int32) - want8)
+        assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+        assert (srgb[..., 3] == 255).all()
+    finally:
+        ctx.close()
