@@ -21,7 +21,8 @@ enum OpKind : int32_t {
     OP_RECT = 2,    // d = amin amax bmin bmax c ; axis
     OP_BOXPRIM = 3, // d = pmin xyz, pmax xyz (the six faces of AxisAlignedBox, src/axis_aligned_box.rs:17-22)
     OP_MSPHERE = 4, // d = center0 xyz, radius, time0, time_range ; leaf.e = center_range xyz
-    OP_MEDIUM = 5,  // d[0] = density ; skip = index of the boundary op (stored after the traversal ops)
+    OP_MEDIUM = 5,  // d[0] = density ; skip = index of the first boundary op (stored after the traversal ops), d[1] = how many:
+                    // one (wrapped) primitive, or a threaded sub-stream of BOX and primitive ops (a list or tree as boundary)
     OP_ENTER = 6,   // enter a transformed subtree: apply chain [chain_start, +chain_count) to the current ray
     OP_EXIT = 7,    // leave it: current ray = world ray transformed by chain [chain_start, +chain_count)
     OP_XFORM = 8    // fused list streams only: d = one DevXform step (tx ty tz s c sign) for the next primitive op

@@ -95,6 +95,8 @@ class Flattener {
         // boundary ops of media are stored behind the traversal stream
         for (auto &op : out_.ops)
             if (op_kind(op.kind) == OP_MEDIUM) op.skip += out_.n_traversal_ops;
+        for (auto &op : boundary_ops_) // the BOX ops of a boundary's sub-stream jump inside it
+            if (op_kind(op.kind) == OP_BOX) op.skip += out_.n_traversal_ops;
         out_.ops.insert(out_.ops.end(), boundary_ops_.begin(), boundary_ops_.end());
         if (out_.ops.empty()) return fail(PT_ERR_INVALID_ARG, "scene flattened to nothing");
 
@@ -277,13 +279,14 @@ class Flattener {
             return PT_OK;
         }
         case PT_H_LIST: {
-            if (!is_root || !local.empty())
-                return fail(PT_ERR_UNSUPPORTED_SCENE, "HitableList is only supported as the scene root");
+            // HitableList::hit (src/hitable.rs:51-62) tests its members in order with a shrinking t_max, which is what a
+            // run of ops in the stream does: a list, wherever it stands, is its members written out. Wrappers above it
+            // distribute over the members: each wrapper transforms the ray once and the winning member's record back,
+            // the same operations on the same values as with the wrapper around every member (t is untouched by them).
             if (n.list_start < 0 || n.list_count < 0 || n.list_start + n.list_count > s_->n_child_index)
                 return fail(PT_ERR_INVALID_ARG, "list range out of bounds");
             for (int k = 0; k < n.list_count; ++k) {
-                int rc = emit(s_->child_index[n.list_start + k], std::vector<SimpleOp>(), full, frame, frame_depth,
-                              false, guard + 1);
+                int rc = emit(s_->child_index[n.list_start + k], local, full, frame, frame_depth, false, guard + 1);
                 if (rc != PT_OK) return rc;
             }
             return PT_OK;
@@ -293,37 +296,14 @@ class Flattener {
                 return fail(PT_ERR_INVALID_ARG, "medium phase function out of range");
             const std::vector<DevXform> steps = compress_chain(local);
             if (full.size() + steps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
-            // boundary: wrappers down to one primitive
-            std::vector<SimpleOp> inner;
-            int b = n.child[0];
-            for (int g = 0;; ++g) {
-                if (!node_ok(b) || g > 255) return fail(PT_ERR_INVALID_ARG, "medium boundary out of range");
-                const pt_hitable &bn = s_->hitables[b];
-                if (bn.kind == PT_H_FLIP) inner.push_back(xf(S_FLIP, 0, 0, 0));
-                else if (bn.kind == PT_H_TRANSLATE) inner.push_back(xf(S_TRANSLATE, bn.f[0], bn.f[1], bn.f[2]));
-                else if (bn.kind == PT_H_ROTATE_Y) inner.push_back(xf(S_ROTATE_Y, bn.f[0], bn.f[1], 0.0));
-                else break;
-                b = bn.child[0];
-            }
-            DevOp bop;
-            DevLeaf bleaf;
-            int rc = PT_OK;
-            if (!geometry_op(b, bop, bleaf, rc))
-                return fail(PT_ERR_UNSUPPORTED_SCENE, "medium boundary must be a (wrapped) sphere, rect or box");
+            // boundary: any subtree of wrappers, lists, trees and primitives, as a sub-stream in the medium's own frame
+            // (ConstantMedium::hit walks it twice, src/volume.rs:30-31); one (wrapped) primitive in every recipe
+            const int32_t bindex = (int32_t)boundary_ops_.size();
+            int rc = emit_boundary(n.child[0], std::vector<SimpleOp>(), 0);
             if (rc != PT_OK) return rc;
-            const std::vector<DevXform> isteps = compress_chain(inner);
-            if (isteps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
-            int32_t istart = store_chain(std::vector<DevXform>(), isteps);
-            bleaf.op = -1; // fixed below
-            bleaf.full_start = istart;
-            bleaf.full_count = (int32_t)isteps.size();
-            bop.kind = op_pack(bleaf.kind, bleaf.axis, (int)isteps.size());
-            bop.chain_start = istart;
-            bop.leaf = (int32_t)out_.leaves.size();
-            out_.leaves.push_back(bleaf);
-            int32_t bindex = (int32_t)boundary_ops_.size();
-            boundary_ops_.push_back(bop);
-
+            const int32_t bcount = (int32_t)boundary_ops_.size() - bindex;
+            if (bcount < 1) return fail(PT_ERR_UNSUPPORTED_SCENE, "medium boundary without a primitive");
+            if (bcount > 1) out_.general_boundaries = true;
             int32_t start = store_chain(full, steps);
             DevLeaf leaf;
             std::memset(&leaf, 0, sizeof(leaf));
@@ -337,6 +317,7 @@ class Flattener {
             std::memset(&op, 0, sizeof(op));
             op.kind = op_pack(OP_MEDIUM, 0, (int)steps.size());
             op.d[0] = n.f[0];
+            op.d[1] = (double)bcount;
             op.skip = bindex; // relocated once the traversal stream is complete
             op.leaf = (int32_t)out_.leaves.size();
             op.chain_start = start + (int32_t)full.size();
@@ -368,6 +349,69 @@ class Flattener {
         }
     }
 
+    // A medium's boundary, into boundary_ops_: primitives carry their wrapper chains (relative to the medium's frame),
+    // a list is its members in order, a tree its BOX ops with skips inside the sub-stream.
+    int emit_boundary(int h, std::vector<SimpleOp> local, int guard) {
+        if (!node_ok(h)) return fail(PT_ERR_INVALID_ARG, "medium boundary out of range");
+        if (guard > 4096) return fail(PT_ERR_INVALID_ARG, "hitable graph too deep or cyclic");
+        const pt_hitable &n = s_->hitables[h];
+        switch (n.kind) {
+        case PT_H_FLIP:
+            local.push_back(xf(S_FLIP, 0, 0, 0));
+            return emit_boundary(n.child[0], local, guard + 1);
+        case PT_H_TRANSLATE:
+            local.push_back(xf(S_TRANSLATE, n.f[0], n.f[1], n.f[2]));
+            return emit_boundary(n.child[0], local, guard + 1);
+        case PT_H_ROTATE_Y:
+            local.push_back(xf(S_ROTATE_Y, n.f[0], n.f[1], 0.0));
+            return emit_boundary(n.child[0], local, guard + 1);
+        case PT_H_LIST:
+            if (n.list_start < 0 || n.list_count < 0 || n.list_start + n.list_count > s_->n_child_index)
+                return fail(PT_ERR_INVALID_ARG, "list range out of bounds");
+            for (int k = 0; k < n.list_count; ++k)
+                if (int rc = emit_boundary(s_->child_index[n.list_start + k], local, guard + 1); rc != PT_OK) return rc;
+            return PT_OK;
+        case PT_H_BVH: {
+            if (!local.empty())
+                return fail(PT_ERR_UNSUPPORTED_SCENE, "a wrapped BVH inside a medium boundary (wrap its members instead)");
+            DevOp box;
+            std::memset(&box, 0, sizeof(box));
+            box.kind = op_pack(OP_BOX, 0, 0);
+            box.leaf = -1;
+            for (int k = 0; k < 6; ++k) box.d[k] = n.f[k];
+            const size_t at = boundary_ops_.size();
+            boundary_ops_.push_back(box);
+            if (int rc = emit_boundary(n.child[0], std::vector<SimpleOp>(), guard + 1); rc != PT_OK) return rc;
+            if (n.child[1] != n.child[0])
+                if (int rc = emit_boundary(n.child[1], std::vector<SimpleOp>(), guard + 1); rc != PT_OK) return rc;
+            boundary_ops_[at].skip = (int32_t)boundary_ops_.size(); // relocated with the rest of the sub-stream
+            return PT_OK;
+        }
+        case PT_H_MEDIUM:
+            return fail(PT_ERR_UNSUPPORTED_SCENE, "a medium as (part of) a medium's boundary");
+        default: {
+            DevOp bop;
+            DevLeaf bleaf;
+            int rc = PT_OK;
+            if (!geometry_op(h, bop, bleaf, rc)) return fail(PT_ERR_INVALID_ARG, "unknown hitable kind");
+            if (rc != PT_OK) return rc;
+            const std::vector<DevXform> isteps = compress_chain(local);
+            if (isteps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
+            if (out_.leaves.size() >= (size_t)(1 << 28)) return fail(PT_ERR_TOO_LARGE, "too many primitives");
+            const int32_t istart = store_chain(std::vector<DevXform>(), isteps);
+            bleaf.op = -1; // set once the boundary ops have their final places
+            bleaf.full_start = istart;
+            bleaf.full_count = (int32_t)isteps.size();
+            bop.kind = op_pack(bleaf.kind, bleaf.axis, (int)isteps.size());
+            bop.chain_start = istart;
+            bop.leaf = (int32_t)out_.leaves.size();
+            out_.leaves.push_back(bleaf);
+            boundary_ops_.push_back(bop);
+            return PT_OK;
+        }
+        }
+    }
+
     const pt_scene_desc *s_;
     FlatScene &out_;
     std::string &err_;
@@ -382,7 +426,8 @@ int flatten_scene(const pt_scene_desc *scene, FlatScene &out, std::string &error
     int rc = f.run();
     if (rc != PT_OK) return rc;
     // boundary leaves point at their op once the boundary ops have been appended
-    for (size_t i = (size_t)out.n_traversal_ops; i < out.ops.size(); ++i) out.leaves[out.ops[i].leaf].op = (int32_t)i;
+    for (size_t i = (size_t)out.n_traversal_ops; i < out.ops.size(); ++i)
+        if (out.ops[i].leaf >= 0) out.leaves[out.ops[i].leaf].op = (int32_t)i;
     // inline geometry and material into every leaf record
     for (DevLeaf &lf : out.leaves) {
         if (lf.op >= 0 && lf.op < (int32_t)out.ops.size())

@@ -18,6 +18,9 @@ struct FlatScene {
     int32_t max_frame_depth = 0; // nesting depth of transformed subtrees
     bool has_medium = false;
     bool has_frames = false;
+    // some medium's boundary is more than one (wrapped) primitive: a list or a tree of them, stored as a threaded
+    // sub-stream behind the traversal stream (DevOp::d[1] of the MEDIUM op holds its length)
+    bool general_boundaries = false;
 };
 
 // Returns PT_OK or PT_ERR_UNSUPPORTED_SCENE / PT_ERR_INVALID_ARG with a message in `error`.

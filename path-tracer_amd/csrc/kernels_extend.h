@@ -20,7 +20,8 @@ struct ExtendArgs {
 // and lanes of a wave visit mostly different nodes.
 // FRAMES / MEDIA say whether the stream holds ENTER/EXIT or MEDIUM ops at all: without them the ray stays
 // loop-invariant during traversal and the code for those ops is not even compiled in.
-template <bool X, bool FRAMES, bool MEDIA>
+// MEDIA: 0 no MEDIUM op, 1 media whose boundary is one primitive, 2 media with a list or tree as boundary.
+template <bool X, bool FRAMES, int MEDIA>
 __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, ExtendArgs a) {
     const bool count = a.counters != nullptr;
     unsigned long long my_nodes = 0, my_prims = 0;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(Queue q, SceneView sv, Extend
             } else if (MEDIA && kind == OP_MEDIUM) {
                 if (count) my_prims += 2;
                 double t;
-                if (medium_hit<X>(sv, *op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t)) {
+                if (medium_hit<X, MEDIA == 2>(sv, *op, o, d, inv, time, a.t_min, closest, pkey, a.depth, t)) {
                     closest = t;
                     best = op->leaf;
                 }

@@ -527,8 +527,36 @@ PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, d
     }
 }
 
-// ConstantMedium::hit (src/volume.rs:24-65). The ray is in the medium's frame once the op's chain is applied.
+// Closest hit over a medium's boundary when that is more than one primitive: the threaded walk of its sub-stream
+// [first, end) of BOX and primitive ops (a HitableList is its members in order, a BvhNode its box and subtrees:
+// src/hitable.rs:51-62, src/bvh.rs:74-99), the ray already in the medium's frame.
 template <bool X>
+PT_DEV bool boundary_hit(const SceneView &sv, int32_t first, int32_t end, D3 o, D3 d, D3 inv, double time, double t_min,
+                         double t_max, double &t_out) {
+    double closest = t_max;
+    bool any = false;
+    int32_t cur = first;
+    while (cur < end) {
+        const DevOp *bop = &sv.ops[cur];
+        if ((bop->kind & 0xff) == OP_BOX) {
+            cur = aabb_hit(bop->d, o, inv, t_min, closest) ? cur + 1 : bop->skip;
+            continue;
+        }
+        double t;
+        int sub;
+        if (prim_hit<X>(sv, *bop, o, d, inv, time, t_min, closest, t, sub)) {
+            closest = t;
+            any = true;
+        }
+        cur += 1;
+    }
+    t_out = closest;
+    return any;
+}
+
+// ConstantMedium::hit (src/volume.rs:24-65). The ray is in the medium's frame once the op's chain is applied.
+// GENERAL: the boundary may be a sub-stream of several ops (op.d[1] of them); otherwise it is one primitive op.
+template <bool X, bool GENERAL = false>
 PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, double time, double t_min,
                        double t_max, uint64_t pkey, uint32_t depth, double &t_out) {
     const int cc = (op.kind >> 16) & 0xff;
@@ -539,7 +567,11 @@ PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv,
     const DevOp &bop = sv.ops[op.skip];
     double t1, t2;
     int sub;
-    if (!X && (bop.kind & 0xff) == OP_SPHERE && ((bop.kind >> 16) & 0xff) == 0) {
+    const int32_t n_boundary = GENERAL ? (int32_t)op.d[1] : 1;
+    if (GENERAL && n_boundary > 1) {
+        if (!boundary_hit<X>(sv, op.skip, op.skip + n_boundary, o, d, inv, time, -kF64Max, kF64Max, t1)) return false;
+        if (!boundary_hit<X>(sv, op.skip, op.skip + n_boundary, o, d, inv, time, t1 + 0.0001, kF64Max, t2)) return false;
+    } else if (!X && (bop.kind & 0xff) == OP_SPHERE && ((bop.kind >> 16) & 0xff) == 0) {
         // A sphere boundary without a chain of its own: both calls of Sphere::hit below evaluate the same two roots
         // (src/sphere.rs:44-81). The first, over (-MAX, MAX), takes the near root r0 (whenever it is finite); the
         // second, over (r0 + 0.0001, MAX), can then only take the far root. Same expressions as sphere_t<false>, once.

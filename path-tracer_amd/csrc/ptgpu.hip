@@ -402,6 +402,12 @@ D3 hunit(D3 a) {
 
 template <bool X, bool FRAMES, bool MEDIA>
 void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
+    if (MEDIA && ctx->flat.general_boundaries) {
+        // a medium whose boundary is a list or a tree: the per-lane walk of the reference's own tree is the one form that
+        // carries the boundary walk (no recipe has such a medium; the forms below keep their registers for those that do)
+        hipLaunchKernelGGL((k_extend<X, FRAMES, 2>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+        return;
+    }
     if (!X && ctx->accel_ok && a.counters != nullptr && (ctx->flags & PT_CFG_COUNT_ACCEL)) {
         // diagnostic: the ray-per-thread form with its node and primitive counters on
         hipLaunchKernelGGL((k_extend_accel<MEDIA, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
@@ -433,7 +439,7 @@ void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &
         hipLaunchKernelGGL((k_extend_scan<X, FRAMES, MEDIA, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, q,
                            ctx->view, a);
     else
-        hipLaunchKernelGGL((k_extend<X, FRAMES, MEDIA>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
+        hipLaunchKernelGGL((k_extend<X, FRAMES, MEDIA ? 1 : 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view, a);
 }
 template <bool X> void launch_extend_x(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &a) {
     const bool frames = ctx->view.has_frames != 0, media = ctx->view.has_medium != 0;
@@ -484,7 +490,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const bool realtime = pp.mode == PT_MODE_REALTIME;
     const bool profile = (ctx->flags & PT_CFG_PROFILE_STAGES) && (ctx->pass_counter % ctx->profile_period == 0);
     const bool count = (ctx->flags & PT_CFG_COUNT_TRAVERSAL) != 0;
-    const bool fused = ctx->fuse && ctx->scan_list && ctx->fuse_ok && !ctx->exact && !count;
+    const bool fused = ctx->fuse && ctx->scan_list && ctx->fuse_ok && !ctx->exact && !count && !ctx->flat.general_boundaries;
     ctx->pass_counter++;
     hipStream_t st = ctx->stream;
     const uint32_t iters = pp.max_depth + 1;
@@ -511,8 +517,9 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const bool pool = fused && ctx->path_pool && (!realtime || n >= ctx->pool_rt_min);
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
-                       ctx->view.n_leaves <= kLdsLeaves;
-    const bool tree = !fused && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count; // offline passes and realtime frames
+                       ctx->view.n_leaves <= kLdsLeaves && !ctx->flat.general_boundaries;
+    const bool tree = !fused && ctx->tree_pool && ctx->accel_ok && !ctx->exact && !count &&
+                      !ctx->flat.general_boundaries; // offline passes and realtime frames
     const bool persistent = fused && !pool;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
@@ -993,7 +1000,8 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
             }
         }
     }
-    ctx->use_scan = f.n_traversal_ops <= ctx->scan_max_ops;
+    // (a medium with a list or tree as boundary is walked by the per-lane kernel alone, whatever the stream's length)
+    ctx->use_scan = f.n_traversal_ops <= ctx->scan_max_ops && !f.general_boundaries;
     // In the wave-uniform traversal a primitive is tested as soon as ONE lane of the wave wants it, so a box test
     // only pays when all 64 rays miss the box. For a handful of primitives that almost never happens, and the box
     // tests cost more than the primitive tests they guard. Fast mode therefore scans the primitive ops alone, in the
@@ -1062,7 +1070,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene) {
         (void)hipFree(ctx->d_accel_spheres);
         ctx->d_accel_spheres = nullptr;
     }
-    if (!ctx->exact && !ctx->scan_list && ctx->use_accel) {
+    if (!ctx->exact && !ctx->scan_list && ctx->use_accel && !f.general_boundaries) {
         Accel acc;
         std::string why;
         if (build_accel(f, acc, why)) {

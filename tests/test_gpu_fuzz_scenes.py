@@ -216,3 +216,84 @@ def test_wrapped_subtree_matches_the_oracle(any_ctx, with_medium):
     finite = np.isfinite(got) & np.isfinite(ref)
     assert (np.isnan(got) == np.isnan(ref)).mean() >= 0.99
     assert (np.isclose(got, ref, rtol=1e-5, atol=1e-7) | ~finite).mean() >= (0.995 if exact else 0.98)
+
+
+def nested_composition(seed, boundary):
+    """Compositions the builder API allows beyond the recipes (src/hitable.rs:40-78, src/volume.rs:30-31): HitableLists
+    inside lists and under wrappers, and (boundary = "list" / "tree") a medium whose boundary is a list of two shapes or
+    a BvhNode of spheres instead of one primitive."""
+    rng = np.random.default_rng(seed)
+    s = ptgpu.Scene(seed=seed)
+    U = lambda lo, hi: float(rng.uniform(lo, hi))
+    white = s.lambertian(s.texture_constant((0.73, 0.73, 0.73)))
+    light = s.diffuse_light(s.texture_constant((12.0, 12.0, 12.0)))
+
+    def mat():
+        k = rng.integers(0, 4)
+        if k <= 1:
+            return s.lambertian(s.texture_constant((U(0.1, 0.9), U(0.1, 0.9), U(0.1, 0.9))))
+        if k == 2:
+            return s.metal((U(0.4, 1.0), U(0.4, 1.0), U(0.4, 1.0)), U(0.0, 0.4))
+        return s.dielectric(1.5)
+
+    def pair():  # two shapes about the origin, as a list
+        a = s.sphere((U(-60, 0), U(-40, 40), U(-40, 40)), U(30, 60), mat())
+        p0 = np.array([U(0, 40), U(-60, 0), U(-60, 0)])
+        b = s.box(p0, p0 + rng.uniform(40, 100, 3), mat())
+        return s.list([a, s.rotate_y(b, U(-40, 40))])
+
+    stage = s.list([s.flip_normals(s.rect(180, 380, 180, 380, 554, 1, light)), s.rect(0, 555, 0, 555, 0, 1, white),
+                    s.flip_normals(s.rect(0, 555, 0, 555, 555, 2, white))])
+    top = [stage]
+    # lists under wrappers, one of them nested once more (RotateY::new takes its child's bounding box, which a list does not
+    # have, src/hitable.rs:63-65,148: a list can stand under Translate and FlipNormals only; its members may be rotated)
+    for _ in range(3):
+        top.append(s.translate(pair(), (U(120, 430), U(60, 400), U(120, 430))))
+    top.append(s.translate(s.list([pair(), s.flip_normals(s.translate(pair(), (70.0, 0.0, 10.0)))]), (U(150, 400), U(100, 300), U(150, 400))))
+    if boundary == "list":
+        shell = s.list([s.sphere((-30.0, 0.0, 0.0), 90.0, white), s.rotate_y(s.box((0.0, -60.0, -60.0), (140.0, 60.0, 60.0), white), 25.0)])
+        top.append(s.constant_medium(s.translate(shell, (280.0, 250.0, 300.0)), 0.02, s.texture_constant((0.9, 0.9, 0.9))))
+    elif boundary == "tree":
+        balls = [s.translate(s.sphere((U(-80, 80), U(-80, 80), U(-80, 80)), U(50, 90), white), (280.0, 250.0, 300.0)) for _ in range(5)]
+        top.append(s.constant_medium(s.bvh(balls, 0.0, 1.0), 0.03, s.texture_constant((0.2, 0.4, 0.9))))
+    s.set_root(s.list(top))
+    s.set_lights([s.rect(180, 380, 180, 380, 554, 1, white)])
+    s.camera = ptgpu.make_camera((278, 278, -760), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 760.0, 0.0, 1.0)
+    return s
+
+
+@pytest.mark.parametrize("seed,boundary", [(401, None), (402, None), (403, "list"), (404, "list"), (405, "tree"), (406, "tree")])
+def test_nested_lists_and_general_medium_boundaries(any_ctx, seed, boundary):
+    ctx, exact = any_ctx
+    scene = nested_composition(seed, boundary)
+    desc = scene.desc()
+    ctx.upload(scene)
+    w = h = 48
+    pix = np.arange(w * h, dtype=np.uint64)
+    primary = ob.camera_rays(scene.camera, w, h, pix, np.zeros(w * h, dtype=np.uint32))
+    ohits, _ = ob.intersect(desc, primary, medium_seed=9)
+    secondary, valid = ob.secondary_rays(ohits, primary)
+    for batch in (primary, secondary[valid]):
+        ref, _ = ob.intersect(desc, batch, medium_seed=9)
+        got = ctx.intersect(batch, medium_seed=9)
+        same = got["prim"] == ref["prim"]
+        assert same.mean() >= (0.9999 if exact else 0.998), f"ids agree on {same.mean():.5f}"
+        both = same & (ref["prim"] >= 0)
+        rel = np.abs(got["t"][both] - ref["t"][both]) / np.maximum(np.abs(ref["t"][both]), 1e-300)
+        assert rel.size == 0 or rel.max() <= (1e-11 if exact else 1e-6), f"t differs by {rel.max():.3e}"
+        assert np.allclose(got["normal"][both], ref["normal"][both], rtol=1e-6, atol=1e-6)
+    if boundary is not None:  # the medium is hit by some of the rays, or the case tests nothing
+        medium_node = max(int(p) for p in np.unique(ohits["prim"]))
+        assert (ohits["normal"][ohits["prim"] == medium_node] == (1.0, 0.0, 0.0)).all() and (ohits["prim"] == medium_node).sum() > 20, (ohits["prim"] == medium_node).sum()
+    for flags in (0, ptgpu.PT_RENDER_BOOK_SEMANTICS):
+        ctx.render(w, h, 3, 12, flags=flags)
+        got = ctx.readback()[..., :3].astype(np.float64)
+        ref, _ = ob.render(desc, scene.camera, w, h, 3, 12, seed=ctx.seed, threads=8, flags=flags)
+        ref = ref[..., :3].astype(np.float64)
+        finite = np.isfinite(got) & np.isfinite(ref)
+        assert (np.isnan(got) == np.isnan(ref)).mean() >= 0.99
+        assert (np.isclose(got, ref, rtol=1e-5, atol=1e-7) | ~finite).mean() >= (0.995 if exact else 0.98)
+    # realtime frames take the same route
+    ctx.reset()
+    ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=0)
+    assert np.isfinite(np.nan_to_num(ctx.readback())).all()

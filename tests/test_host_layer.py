@@ -191,19 +191,30 @@ def test_scene_build_is_deterministic_in_the_seed():
     assert fa != [tuple(c.hitables[h].f) for h in range(min(a.n_hitables, c.n_hitables))]
 
 
-def test_flattener_rejects_unsupported_graphs():
+def test_flattener_takes_nested_lists_and_rejects_what_it_cannot_walk():
     s = ptgpu.Scene()
     m = s.lambertian(s.texture_constant((1, 1, 1)))
-    a, b = s.sphere((0, 0, 0), 1, m), s.sphere((3, 0, 0), 1, m)
+    a, b, c = s.sphere((0, 0, 0), 1, m), s.sphere((3, 0, 0), 1, m), s.sphere((6, 0, 0), 1, m)
     lst = s.list([a, b])
-    moved = s.translate(lst, (1, 0, 0))            # a wrapped HitableList has no bounding box in the reference either
-    s.set_root(moved)
-    s.set_lights([a])
-    with pytest.raises(ptgpu.PtError) as e:
-        s.flatten_info()
-    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED_SCENE
     s.set_root(lst)
+    s.set_lights([a])
     assert s.flatten_info()["n_ops"] == 2
+    # a HitableList under a wrapper, and inside another list: its members written out, the wrapper on each of them
+    moved = s.translate(lst, (1, 0, 0))
+    s.set_root(s.list([moved, c]))
+    info = s.flatten_info()
+    assert info["n_ops"] == 3 and info["n_leaves"] == 3 and info["n_xforms"] == 2
+    # a medium bounded by a list (two primitives): a sub-stream behind the traversal ops
+    fog = s.constant_medium(s.list([s.sphere((0, 0, 0), 2, m), s.box((-1, -1, -1), (4, 1, 1), m)]), 0.1, s.texture_constant((1, 1, 1)))
+    s.set_root(s.list([fog, c]))
+    assert s.flatten_info()["n_ops"] == 2 and s.flatten_info()["n_leaves"] == 4
+    # what the walk of a boundary does not carry: a tree under a wrapper, a medium inside a boundary
+    tree = s.bvh([s.sphere((0, 0, 0), 1, m), s.sphere((2, 0, 0), 1, m)])
+    for bad in (s.translate(tree, (1, 0, 0)), s.constant_medium(a, 0.2, s.texture_constant((1, 1, 1)))):
+        s.set_root(s.constant_medium(bad, 0.1, s.texture_constant((1, 1, 1))))
+        with pytest.raises(ptgpu.PtError) as e:
+            s.flatten_info()
+        assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED_SCENE
 
 
 def test_stripe_partition_covers_the_image_once():
