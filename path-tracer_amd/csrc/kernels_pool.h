@@ -316,6 +316,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
     int sp = 0;
 #ifdef PT_POOL_TIMING
     long long tm_refill = 0, tm_inner = 0, tm_leaf = 0, tm_shade = 0, tm_rounds = 0, tm_shades = 0, tm_lanes = 0, tm0 = clock64();
+    long long tm_leaf_steps = 0, tm_leaf_box = 0, tm_leaf_sph = 0, tm_leaf_med = 0, tm_leaf_chain = 0, tm_leaf_all = 0, tm_inner_steps = 0, tm_inner_lanes = 0;
 #define PT_TICK(acc) { long long t_ = clock64(); acc += t_ - tm0; tm0 = t_; }
     for (int k = lane; k < 3 * kShadePhases + 1; k += 64) shade_clock()[k] = 0;
 #else
@@ -446,6 +447,10 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                 }
             }
             const uint32_t n_inner = (uint32_t)__popcll(__ballot(has && node >= 0));
+#ifdef PT_POOL_TIMING
+            tm_inner_steps += 1;
+            tm_inner_lanes += n_inner;
+#endif
             if (n_inner == 0 || n_inner < inner_min) break;
         }
         PT_TICK(tm_inner)
@@ -464,6 +469,17 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     }
                 } else {
                     const DevOp op = prims[k];
+#ifdef PT_POOL_TIMING
+                    { // lanes per primitive kind in this step of the leaf loop
+                        const int kd = op.kind & 0xff;
+                        tm_leaf_steps += 1;
+                        tm_leaf_box += __popcll(__ballot(kd == OP_BOXPRIM));
+                        tm_leaf_sph += __popcll(__ballot(kd == OP_SPHERE || kd == OP_MSPHERE));
+                        tm_leaf_med += __popcll(__ballot(kd == OP_MEDIUM));
+                        tm_leaf_chain += __popcll(__ballot(((op.kind >> 16) & 0xff) != 0));
+                        tm_leaf_all += __popcll(__ballot(true));
+                    }
+#endif
                     bool hit;
                     if (MEDIA && (op.kind & 0xff) == OP_MEDIUM)
                         hit = medium_hit<false>(sv, op, o, d, inv, time, 0.001, closest, pkey, depth, t);
@@ -548,6 +564,12 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
         printf("tree pool timing: rounds %lld shade rounds %lld lanes/shade %.1f cycles/round refill %.0f inner %.0f leaf %.0f shade %.0f (per shade round %.0f)\n",
                tm_rounds, tm_shades, (double)tm_lanes / (double)(tm_shades ? tm_shades : 1), (double)tm_refill / tm_rounds, (double)tm_inner / tm_rounds,
                (double)tm_leaf / tm_rounds, (double)tm_shade / tm_rounds, (double)tm_shade / (double)(tm_shades ? tm_shades : 1));
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("  inner steps/round %.2f lanes left on inner nodes after a step %.1f | leaf-loop steps/round %.2f lanes/step %.1f: box %.1f sphere %.1f medium %.1f (with a chain %.1f)\n",
+               (double)tm_inner_steps / tm_rounds, (double)tm_inner_lanes / (double)(tm_inner_steps ? tm_inner_steps : 1),
+               (double)tm_leaf_steps / tm_rounds, (double)tm_leaf_all / (double)(tm_leaf_steps ? tm_leaf_steps : 1),
+               (double)tm_leaf_box / (double)(tm_leaf_steps ? tm_leaf_steps : 1), (double)tm_leaf_sph / (double)(tm_leaf_steps ? tm_leaf_steps : 1),
+               (double)tm_leaf_med / (double)(tm_leaf_steps ? tm_leaf_steps : 1), (double)tm_leaf_chain / (double)(tm_leaf_steps ? tm_leaf_steps : 1));
     if (blockIdx.x == 7 && threadIdx.x == 0) {
         const long long *c = shade_clock();
         for (int k = 0; k < kShadePhases; ++k)
