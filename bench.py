@@ -160,7 +160,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode leg")
     ap.add_argument("--no-extend", action="store_true", help="skip the extend-stage leg")
-    ap.add_argument("--cfg-flags", type=int, default=0, help="extra PT_CFG_* bits for the timed context (8 = PT_CFG_FAT_RECORDS, A/B runs)")
+    ap.add_argument("--cfg-flags", type=int, default=0, help="extra PT_CFG_* bits for the timed context (8 = PT_CFG_FAT_RECORDS, 32 = PT_CFG_WIDE_NODES: A/B runs)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the legs over the other configurations (config.workloads)")
     ap.add_argument("--extend-cloud", type=int, default=1000000,
                     help="spheres of the second extend scene (0 skips it; its host build and oracle pass take ~1 min)")

@@ -182,9 +182,10 @@ typedef struct pt_tuning {
     uint32_t pool_refill;          /* path pool: free path slots (1..64) at which a wave takes new camera samples */
     uint32_t pool_chunk;           /* pool kernels: path ids a wave takes from the pass's counter at a time (64..2^20) */
     uint32_t pool_grid;            /* pool kernels: workgroups per resident slot (1..256) */
-    uint32_t tree_refill, tree_inner, tree_shade; /* tree pool thresholds in lanes (1..64): refill at / stay on inner
-                                                     nodes while (default 16, trees of 32 768 nodes and more 24,
-                                                     realtime frames 4) / shade when this many lanes (default 32,
+    uint32_t tree_refill, tree_inner, tree_shade; /* tree pool thresholds in lanes (1..64): refill at (default 16,
+                                                     big trees of plain spheres 4) / stay on inner nodes while
+                                                     (default 16, trees of 32 768 nodes and more 24, of plain
+                                                     spheres 28, realtime frames 4) / shade when this many lanes (default 32,
                                                      realtime frames 48) ... */
     uint32_t tree_trav_plus1;      /* ... or at most this many minus one (1..65) still traverse */
     uint32_t accel_form;           /* extend stage over the SAH tree: 1 = a ray per thread, 2 = refilled lane pool */
@@ -213,6 +214,9 @@ typedef struct pt_config {
 
 #define PT_CFG_FAT_RECORDS 8u /* diagnostic: a scene of plain spheres alone is traced through the general primitive and
                                  leaf records instead of the compact 64-byte sphere records (same image, for A/B runs) */
+
+#define PT_CFG_WIDE_NODES 32u /* diagnostic: the one-launch pass over a big tree of plain spheres reads the 64-byte nodes
+                                 instead of their 32-byte form (same image, for A/B runs) */
 
 #define PT_CFG_COUNT_ACCEL 16u /* diagnostic, fast mode: pt_intersect* count the node records read and the primitives
                                   tested in the fast-mode tree (pt_stats.node_visits / prim_tests); the batch then runs

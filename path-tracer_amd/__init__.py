@@ -44,6 +44,7 @@ PT_CFG_PROFILE_STAGES = 1
 PT_CFG_COUNT_TRAVERSAL = 2
 PT_CFG_EXACT = 4
 PT_CFG_FAT_RECORDS = 8
+PT_CFG_WIDE_NODES = 32
 PT_CFG_COUNT_ACCEL = 16
 
 # pt_hitable_kind

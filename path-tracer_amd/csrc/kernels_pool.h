@@ -16,6 +16,7 @@
 struct PoolConsts {
     CameraDev cam;
     PassParams pp;
+    AccelGrid grid; // of the 32-byte nodes, for the kernels that read those
 };
 // Puts a pass's constants where the pool kernels read them. They arrive as kernel arguments, i.e. with the launch packet:
 // a copy from pageable host memory costs the host a staging copy and a wait of its own per pass, which a realtime frame
@@ -282,7 +283,9 @@ template <> struct TreePoolTexLds<2> {
 // SPH: the scene is plain spheres alone and `prims` holds their compact records (DevSphere) in leaf order: the leaf
 // test and the vertex read the same 64 bytes, and the hit id is the record's index. Same arithmetic on the same
 // values as the general form: images are bit-identical.
-template <int TEX, bool MEDIA, bool RT = false, bool SPH = false>
+// QUANT: `nodes` holds the tree in its 32-byte form (AccelNodeQ, planes on consts->grid): two 16-byte reads per lane and
+// node visit instead of four, one FMA per plane with per-ray constants instead of a subtraction and a product.
+template <int TEX, bool MEDIA, bool RT = false, bool SPH = false, bool QUANT = false>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH_WAVES : PT_SHADE_WAVES)) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
@@ -322,8 +325,15 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
 #else
 #define PT_TICK(acc)
 #endif
+    QuantRay qr{o, o};
     auto start_ray = [&]() { // (o, d) hold a new ray
-        inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+        if constexpr (QUANT) {
+            const PoolConsts *pc = consts;
+            asm volatile("" : "+s"(pc)); // keeps the loads in this block
+            qr = quant_ray(pc->grid, o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
+        } else {
+            inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+        }
         closest = kF64Max;
         best = -1;
         sp = 0;
@@ -431,11 +441,21 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
         // traversal: inner nodes for as long as at least `inner_min` lanes are on one, then the leaves
         for (;;) {
             if (has && node >= 0) {
-                const AccelNode &nd = nodes[node];
                 double t0, t1;
-                const bool h0 = accel_box(nd.lo[0], nd.hi[0], o, inv, 0.001, closest, t0);
-                const bool h1 = accel_box(nd.lo[1], nd.hi[1], o, inv, 0.001, closest, t1);
-                const int32_t c0 = nd.child[0], c1 = nd.child[1];
+                bool h0, h1;
+                int32_t c0, c1;
+                if constexpr (QUANT) {
+                    const AccelNodeQ nq = ((const AccelNodeQ *)nodes)[node];
+                    accel_boxes_q(nq, qr, 0.001, closest, h0, h1, t0, t1);
+                    c0 = nq.child[0];
+                    c1 = nq.child[1];
+                } else {
+                    const AccelNode &nd = nodes[node];
+                    h0 = accel_box(nd.lo[0], nd.hi[0], o, inv, 0.001, closest, t0);
+                    h1 = accel_box(nd.lo[1], nd.hi[1], o, inv, 0.001, closest, t1);
+                    c0 = nd.child[0];
+                    c1 = nd.child[1];
+                }
                 if (h0 && h1) {
                     const bool first0 = t0 <= t1;
                     stack[sp++][threadIdx.x] = first0 ? c1 : c0;

@@ -161,7 +161,8 @@ struct pt_ctx {
     uint32_t persist_factor = 1;
     bool tree_pool = true;        // offline passes of tree scenes as one k_tree_pool launch
     uint32_t tree_tuning[4] = {16, 16, 32, 4}; // refill at / inner min / shade min / traversing min
-    bool tree_inner_set = false;               // inner min came from pt_config (else big trees use 24, realtime frames 4)
+    bool tree_refill_set = false;              // refill at came from pt_config (else big trees of plain spheres use 4)
+    bool tree_inner_set = false;               // inner min came from pt_config (else big trees use 24, of plain spheres 28, realtime frames 4)
     bool tree_shade_set = false;               // shade min came from pt_config (else realtime frames use 48)
     void *d_pool_consts = nullptr;
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
@@ -183,6 +184,7 @@ struct pt_ctx {
     void *d_accel_nodes_q = nullptr; // the nodes in their 32-byte form (trees of kAccelQuantFrom nodes and more), else null
     void *d_accel_spheres = nullptr; // the primitives as compact DevSphere records in leaf order (scenes of plain spheres alone), else null
     bool compact_spheres = true;     // use them (PT_CFG_FAT_RECORDS turns them off, for A/B runs)
+    bool quant_pool = true;          // the sphere tree pool reads the 32-byte nodes where they exist (PT_CFG_WIDE_NODES turns that off, for A/B runs)
     AccelGrid accel_grid_q{};
     int32_t n_accel_nodes = 0;
     std::vector<std::pair<int32_t, int32_t>> accel_levels; // refit order (deepest level first): index ranges of d_accel_levels, or node id ranges when that is null
@@ -527,7 +529,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
             if (hipError_t e = counted_malloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp}, (PoolConsts *)ctx->d_pool_consts);
+        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp, ctx->accel_grid_q}, (PoolConsts *)ctx->d_pool_consts);
         return hipGetLastError();
     };
     if (pool || tree || xpool) {
@@ -627,10 +629,15 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         // A realtime frame gives a wave some hundred paths in all, and its lanes thin out soon: the few that are still on
         // inner nodes must keep stepping, and shading waits for a fuller batch (1080p frames: final scene 616 -> 668 per
         // second, RTiOW 2 307 -> 2 528).
+        // The variant for plain spheres on a big tree (32-byte nodes, a vertex of a few hundred instructions) takes new paths
+        // as soon as four lanes are free and leaves its inner nodes at 28 lanes (one million spheres: 710 -> 773 Mpaths/s
+        // against 16 / 24; refill at 1 .. 6 within 0.5 %, inner 20 / 32 / 40: 742 / 763 / 699).
+        const bool big = ctx->n_accel_nodes >= kAccelQuantFrom;
         const uint32_t inner_min = ctx->tree_inner_set ? ctx->tree_tuning[1]
-                                   : realtime ? 4u : (ctx->n_accel_nodes >= kAccelQuantFrom ? 24u : ctx->tree_tuning[1]);
+                                   : realtime ? 4u : (big ? (spheres ? 28u : 24u) : ctx->tree_tuning[1]);
         const uint32_t shade_min = ctx->tree_shade_set ? ctx->tree_tuning[2] : (realtime ? 48u : ctx->tree_tuning[2]);
-        const uint32_t tuning = ctx->tree_tuning[0] | (inner_min << 8) | (shade_min << 16) | (ctx->tree_tuning[3] << 24);
+        const uint32_t refill_at = ctx->tree_refill_set ? ctx->tree_tuning[0] : ((big && spheres && !realtime) ? 4u : ctx->tree_tuning[0]);
+        const uint32_t tuning = refill_at | (inner_min << 8) | (shade_min << 16) | (ctx->tree_tuning[3] << 24);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
@@ -649,7 +656,16 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                    (const DevOp *)ctx->d_accel_spheres, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
                                    ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
             };
-            if (realtime) launch_sph(k_tree_pool<0, false, true, true>);
+            auto launch_sph_q = [&](auto kernel) { // big trees: the 32-byte nodes
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes_q,
+                                   (const DevOp *)ctx->d_accel_spheres, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
+                                   ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
+            };
+            const bool quant = ctx->d_accel_nodes_q != nullptr && ctx->quant_pool;
+            if (quant) {
+                if (realtime) launch_sph_q(k_tree_pool<0, false, true, true, true>);
+                else launch_sph_q(k_tree_pool<0, false, false, true, true>);
+            } else if (realtime) launch_sph(k_tree_pool<0, false, true, true>);
             else launch_sph(k_tree_pool<0, false, false, true>);
         } else
         with_tex(ctx->tex, [&](auto T) {
@@ -789,7 +805,7 @@ bool apply_tuning(pt_ctx *ctx, const pt_tuning &t) {
     if (t.pool_chunk) { if (!in(t.pool_chunk, 64, 1u << 20)) return false; ctx->pool_chunk = t.pool_chunk; }
     if (t.pool_grid) { if (!in(t.pool_grid, 1, 256)) return false; ctx->pool_grid = t.pool_grid; }
     // a refill threshold above 64 would never be met: the kernel could not end
-    if (t.tree_refill) { if (!in(t.tree_refill, 1, 64)) return false; ctx->tree_tuning[0] = t.tree_refill; }
+    if (t.tree_refill) { if (!in(t.tree_refill, 1, 64)) return false; ctx->tree_tuning[0] = t.tree_refill; ctx->tree_refill_set = true; }
     if (t.tree_inner) { if (!in(t.tree_inner, 1, 64)) return false; ctx->tree_tuning[1] = t.tree_inner; ctx->tree_inner_set = true; }
     if (t.tree_shade) { if (!in(t.tree_shade, 1, 64)) return false; ctx->tree_tuning[2] = t.tree_shade; ctx->tree_shade_set = true; }
     if (t.tree_trav_plus1) { if (!in(t.tree_trav_plus1, 1, 65)) return false; ctx->tree_tuning[3] = t.tree_trav_plus1 - 1; }
@@ -863,6 +879,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out) {
     ctx->flags = cfg->flags;
     ctx->exact = (cfg->flags & PT_CFG_EXACT) != 0;
     ctx->compact_spheres = (cfg->flags & PT_CFG_FAT_RECORDS) == 0;
+    ctx->quant_pool = (cfg->flags & PT_CFG_WIDE_NODES) == 0;
     pt_tuning tune;
     std::memset(&tune, 0, sizeof(tune));
     if (cfg->struct_size == sizeof(pt_config)) tune = cfg->tuning;

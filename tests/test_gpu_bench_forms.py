@@ -199,7 +199,10 @@ def test_compact_sphere_records_give_the_same_image(case):
         scene = _sphere_scene(300, translated=case == "translated", textured=case == "textured")
         w, h, spp, depth = 96, 64, 4, 12
     images = {}
-    for label, flags in (("compact", 0), ("fat", ptgpu.PT_CFG_FAT_RECORDS)):
+    forms = [("compact", 0), ("fat", ptgpu.PT_CFG_FAT_RECORDS)]
+    if case == "cloud":  # a tree big enough for the 32-byte nodes: the compact records over either node form
+        forms.append(("wide_nodes", ptgpu.PT_CFG_WIDE_NODES))
+    for label, flags in forms:
         ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 18, flags=flags)
         ctx.upload(scene)
         ctx.render(w, h, spp, depth)
@@ -214,8 +217,9 @@ def test_compact_sphere_records_give_the_same_image(case):
         rebuilt = ctx.readback()
         images[label] = (offline, realtime, rebuilt)
         ctx.close()
-    for a, b in zip(images["compact"], images["fat"]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for label, _ in forms[1:]:
+        for a, b in zip(images["compact"], images[label]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), label
     # a tree over the same primitives finds the same hits (exact ties aside): the rebuilt tree's image is the same too
     assert np.array_equal(images["compact"][0].view(np.uint32), images["compact"][2].view(np.uint32))
     # and the compact form against the oracle on the small scenes
