@@ -450,6 +450,59 @@ __device__ __forceinline__ void accel_boxes_q(const AccelNodeQ &n, const QuantRa
     h1 = t1 <= f1;
 }
 
+// The same slab tests in f32, for the kernels whose inner-node step is bound by the vector ALU (an f64 min, max, FMA or
+// conversion issues at half the rate of its f32 form, and there is no three-operand min / max in f64). They stay
+// conservative by construction: a plane's distance q A + B (A = cell / d, B = (gmin - o) / d) evaluated in f32 from the
+// rounded constants is off by less than E = (65536 |A| + |B|) 2^-21 on that axis (three roundings of 2^-24 relative to
+// the larger of the two terms, with a factor of two to spare), so the near side of an axis is taken from planes
+// evaluated with B - E and the far side from planes evaluated with B + E: the interval only grows, a box the f64 test
+// accepts is accepted here, and since boxes only cull, every ray finds the hit it finds through the f64 test. The ray
+// interval is widened the same way: t_min rounded down, the closest hit rounded up. 1 / d is clamped to +-1e25 (f32
+// holds 65536 A and B up to scenes of 1e8 units; a parallel axis gives +-huge distances with the right sign).
+struct QuantRayF {
+    float a[3], bl[3], bh[3];
+};
+__device__ __forceinline__ QuantRayF quant_ray_f(const AccelGrid &g, D3 o, D3 inv) {
+    const double big = 1.0e25;
+    const double i[3] = {fmin(fmax(inv.x, -big), big), fmin(fmax(inv.y, -big), big), fmin(fmax(inv.z, -big), big)};
+    const double og[3] = {g.gmin[0] - o.x, g.gmin[1] - o.y, g.gmin[2] - o.z};
+    QuantRayF r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double A = g.cell[k] * i[k], B = og[k] * i[k];
+        const double E = (65536.0 * fabs(A) + fabs(B)) * 4.76837158203125e-07; // 2^-21
+        r.a[k] = (float)A;
+        r.bl[k] = (float)(B - E);
+        r.bh[k] = (float)(B + E);
+    }
+    return r;
+}
+// t_max_up: the closest hit so far, not rounded down
+__device__ __forceinline__ void accel_boxes_qf(const AccelNodeQ &n, const QuantRayF &r, float t_max_up, bool &h0, bool &h1,
+                                               float &t0, float &t1) {
+    const float t_min_down = 0.000999f; // below the 0.001 of every ray interval of a render
+    float nr[2][3], fr[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float ql = (float)(uint32_t)n.lo[k][c], qh = (float)(uint32_t)n.hi[k][c];
+            nr[c][k] = fminf(__builtin_fmaf(ql, r.a[k], r.bl[k]), __builtin_fmaf(qh, r.a[k], r.bl[k]));
+            fr[c][k] = fmaxf(__builtin_fmaf(ql, r.a[k], r.bh[k]), __builtin_fmaf(qh, r.a[k], r.bh[k]));
+        }
+    t0 = fmaxf(fmaxf(nr[0][0], nr[0][1]), fmaxf(nr[0][2], t_min_down));
+    t1 = fmaxf(fmaxf(nr[1][0], nr[1][1]), fmaxf(nr[1][2], t_min_down));
+    const float f0 = fminf(fminf(fr[0][0], fr[0][1]), fminf(fr[0][2], t_max_up));
+    const float f1 = fminf(fminf(fr[1][0], fr[1][1]), fminf(fr[1][2], t_max_up));
+    h0 = t0 <= f0;
+    h1 = t1 <= f1;
+}
+// an f64 distance as an f32 that is not below it (positive values; the largest f64 becomes +inf)
+__device__ __forceinline__ float f32_not_below(double t) {
+    const float f = (float)t;
+    return __builtin_fmaf(f, 1.1920929e-07f, f); // + 2^-23 f: a step or two up
+}
+
 // COUNT: node records read and primitives tested are added to a.counters (PT_CFG_COUNT_ACCEL). The lane pool form
 // below walks the same tree in the same order ray by ray, so the counts describe both.
 template <bool MEDIA, bool COUNT = false>

@@ -284,12 +284,17 @@ template <> struct TreePoolTexLds<2> {
 // test and the vertex read the same 64 bytes, and the hit id is the record's index. Same arithmetic on the same
 // values as the general form: images are bit-identical.
 // QUANT: `nodes` holds the tree in its 32-byte form (AccelNodeQ, planes on consts->grid): two 16-byte reads per lane and
-// node visit instead of four, one FMA per plane with per-ray constants instead of a subtraction and a product.
+// node visit instead of four, and the slab tests in f32, widened so that they accept whatever the f64 tests accept
+// (accel_boxes_qf); -DPT_QUANT_F32=0 builds the f64 form of the same tests for A/B runs.
+#ifndef PT_QUANT_F32
+#define PT_QUANT_F32 1
+#endif
 template <int TEX, bool MEDIA, bool RT = false, bool SPH = false, bool QUANT = false>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH_WAVES : PT_SHADE_WAVES)) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk_arg) {
+    static_assert(!QUANT || SPH, "the 32-byte nodes are read by the variant for plain spheres only");
     const uint32_t chunk = chunk_arg & 0x7fffffffu;
     const bool static_chunks = (chunk_arg >> 31) != 0u; // RT: one chunk per wave, dealt by wave index
     bool started = false;
@@ -325,12 +330,22 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
 #else
 #define PT_TICK(acc)
 #endif
+#if PT_QUANT_F32
+    QuantRayF qr{};
+    float closest_up = 0.0f; // the closest hit so far as an f32 that is not below it
+#else
     QuantRay qr{o, o};
+#endif
     auto start_ray = [&]() { // (o, d) hold a new ray
         if constexpr (QUANT) {
             const PoolConsts *pc = consts;
             asm volatile("" : "+s"(pc)); // keeps the loads in this block
+#if PT_QUANT_F32
+            qr = quant_ray_f(pc->grid, o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
+            closest_up = __builtin_inff();
+#else
             qr = quant_ray(pc->grid, o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
+#endif
         } else {
             inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
         }
@@ -441,23 +456,30 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
         // traversal: inner nodes for as long as at least `inner_min` lanes are on one, then the leaves
         for (;;) {
             if (has && node >= 0) {
-                double t0, t1;
-                bool h0, h1;
+                bool h0, h1, first0;
                 int32_t c0, c1;
                 if constexpr (QUANT) {
                     const AccelNodeQ nq = ((const AccelNodeQ *)nodes)[node];
+#if PT_QUANT_F32
+                    float t0, t1;
+                    accel_boxes_qf(nq, qr, closest_up, h0, h1, t0, t1);
+#else
+                    double t0, t1;
                     accel_boxes_q(nq, qr, 0.001, closest, h0, h1, t0, t1);
+#endif
+                    first0 = t0 <= t1;
                     c0 = nq.child[0];
                     c1 = nq.child[1];
                 } else {
+                    double t0, t1;
                     const AccelNode &nd = nodes[node];
                     h0 = accel_box(nd.lo[0], nd.hi[0], o, inv, 0.001, closest, t0);
                     h1 = accel_box(nd.lo[1], nd.hi[1], o, inv, 0.001, closest, t1);
+                    first0 = t0 <= t1;
                     c0 = nd.child[0];
                     c1 = nd.child[1];
                 }
                 if (h0 && h1) {
-                    const bool first0 = t0 <= t1;
                     stack[sp++][threadIdx.x] = first0 ? c1 : c0;
                     node = first0 ? c0 : c1;
                 } else if (h0 || h1) {
@@ -486,6 +508,9 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     if (sphere_t<false>(d3(sp->c[0], sp->c[1], sp->c[2]), sp->radius, o, d, 0.001, closest, t, sub)) {
                         closest = t;
                         best = k | (sub << 28);
+#if PT_QUANT_F32
+                        if constexpr (QUANT) closest_up = f32_not_below(t);
+#endif
                     }
                 } else {
                     const DevOp op = prims[k];
