@@ -477,10 +477,9 @@ __device__ __forceinline__ QuantRayF quant_ray_f(const AccelGrid &g, D3 o, D3 in
     }
     return r;
 }
-// t_max_up: the closest hit so far, not rounded down
-__device__ __forceinline__ void accel_boxes_qf(const AccelNodeQ &n, const QuantRayF &r, float t_max_up, bool &h0, bool &h1,
-                                               float &t0, float &t1) {
-    const float t_min_down = 0.000999f; // below the 0.001 of every ray interval of a render
+// t_min_down, t_max_up: the ray interval (t_max = the closest hit so far), rounded outward
+__device__ __forceinline__ void accel_boxes_qf(const AccelNodeQ &n, const QuantRayF &r, float t_min_down, float t_max_up,
+                                               bool &h0, bool &h1, float &t0, float &t1) {
     float nr[2][3], fr[2][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -497,10 +496,14 @@ __device__ __forceinline__ void accel_boxes_qf(const AccelNodeQ &n, const QuantR
     h0 = t0 <= f0;
     h1 = t1 <= f1;
 }
-// an f64 distance as an f32 that is not below it (positive values; the largest f64 becomes +inf)
+// an f64 distance as an f32 that is not below / not above it (beyond the f32 range: +-inf)
 __device__ __forceinline__ float f32_not_below(double t) {
     const float f = (float)t;
-    return __builtin_fmaf(f, 1.1920929e-07f, f); // + 2^-23 f: a step or two up
+    return __builtin_fmaf(fabsf(f), 1.1920929e-07f, f); // + 2^-23 |f|: a step or two up
+}
+__device__ __forceinline__ float f32_not_above(double t) {
+    const float f = (float)t;
+    return __builtin_fmaf(fabsf(f), -1.1920929e-07f, f);
 }
 
 // COUNT: node records read and primitives tested are added to a.counters (PT_CFG_COUNT_ACCEL). The lane pool form
@@ -620,7 +623,9 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
     bool has = false;                    // this lane holds a ray in flight
     uint32_t my_i = 0;
     D3 o = d3(0, 0, 0), d = o, inv = o;
-    QuantRay qr{o, o};
+    QuantRayF qr{};
+    float closest_up = 0.0f;                             // QUANT: the closest hit so far as an f32 that is not below it
+    const float t_min_down = f32_not_above(a.t_min), t_max_up = f32_not_below(a.t_max);
     double time = 0.0, closest = 0.0;
     uint64_t pkey = 0;
     int32_t best = -1, node = kDone;
@@ -650,7 +655,10 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
                     time = q.tm(my_i);
                     if (MEDIA) pkey = (a.key_mode == 0) ? q.key(my_i) : intersect_key(a.medium_seed, my_i);
                     inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-                    if constexpr (QUANT) qr = quant_ray(grid, o, inv);
+                    if constexpr (QUANT) {
+                        qr = quant_ray_f(grid, o, inv);
+                        closest_up = t_max_up;
+                    }
                     closest = a.t_max;
                     best = -1;
                     sp = 0;
@@ -666,23 +674,25 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
         // `inner_min` lanes are still on inner nodes
         for (;;) {
             if (has && node >= 0) {
-                double t0, t1;
-                bool h0, h1;
+                bool h0, h1, first0;
                 int32_t c0, c1;
                 if constexpr (QUANT) {
                     const AccelNodeQ n = nodes_q[node];
-                    accel_boxes_q(n, qr, a.t_min, closest, h0, h1, t0, t1);
+                    float t0, t1;
+                    accel_boxes_qf(n, qr, t_min_down, closest_up, h0, h1, t0, t1);
+                    first0 = t0 <= t1;
                     c0 = n.child[0];
                     c1 = n.child[1];
                 } else {
                     const AccelNode &n = nodes[node];
+                    double t0, t1;
                     h0 = accel_box(n.lo[0], n.hi[0], o, inv, a.t_min, closest, t0);
                     h1 = accel_box(n.lo[1], n.hi[1], o, inv, a.t_min, closest, t1);
+                    first0 = t0 <= t1;
                     c0 = n.child[0];
                     c1 = n.child[1];
                 }
                 if (h0 && h1) {
-                    const bool first0 = t0 <= t1;
                     stack[sp++][threadIdx.x] = first0 ? c1 : c0;
                     node = first0 ? c0 : c1;
                 } else if (h0 || h1) {
@@ -709,6 +719,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : 5) void k_extend_accel_pool(Que
                 if (hit) {
                     closest = t;
                     best = op.leaf | (sub << 28);
+                    if constexpr (QUANT) closest_up = f32_not_below(t);
                 }
             }
             node = sp ? stack[--sp][threadIdx.x] : kDone;

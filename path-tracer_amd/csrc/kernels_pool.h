@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     const AccelNodeQ nq = ((const AccelNodeQ *)nodes)[node];
 #if PT_QUANT_F32
                     float t0, t1;
-                    accel_boxes_qf(nq, qr, closest_up, h0, h1, t0, t1);
+                    accel_boxes_qf(nq, qr, 0.000999f, closest_up, h0, h1, t0, t1); // (below the 0.001 of a render's rays)
 #else
                     double t0, t1;
                     accel_boxes_q(nq, qr, 0.001, closest, h0, h1, t0, t1);
