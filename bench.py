@@ -72,13 +72,24 @@ def roofline_block(pt, st, model):
     achieved = flop_unit * units_per_launch / launch_s / 1e12 if (flop_unit and launch_s > 0) else None
     hbm_unit = model.get("hbm_bytes_per_unit")
     traffic = hbm_unit * units_per_launch if hbm_unit is not None else None
+    fp64_frac = (achieved / FP64_VECTOR_PEAK_TFLOPS) if achieved is not None else None
+    hbm_gbs = (traffic / launch_s / 1e9) if (traffic is not None and launch_s > 0) else None
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS if hbm_gbs is not None else None
+    # The roof a kernel is priced against is the one it stands closer to: the f64 issue rate of the vector pipe for the
+    # kernels that keep their scene in caches and their paths in registers, the memory system for the kernel that walks a
+    # tree of a million nodes (its slab tests are f32, so its f64 flop say little; what it moves is node and primitive
+    # records, 32 and 64 bytes at a time, most of them from L2 and the last-level cache).
+    memory_bound = hbm_frac is not None and fp64_frac is not None and hbm_frac > fp64_frac
+    head = ({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+             "achieved_is": "bytes the L2s request from the fabric (measured, see traffic_note), per launch, over the launch's "
+                            "duration: node and primitive records as this kernel reads them, not SURVEY's per-visit model"}
+            if memory_bound else
+            {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64_frac})
     return {
-        "bound": "fp64_valu",
+        **head,
         "kernel": model.get("kernel_full_name", kernel),
-        "achieved": achieved,
-        "peak": FP64_VECTOR_PEAK_TFLOPS,
-        "unit": "TFLOP/s",
-        "frac": (achieved / FP64_VECTOR_PEAK_TFLOPS) if achieved is not None else None,
+        "fp64_valu_TFLOPs": achieved,
+        "fp64_valu_frac": fp64_frac,
         "traffic": traffic,
         "traffic_note": "bytes the L2s request from the fabric per launch (2 x FETCH_SIZE + WRITE_SIZE): hits in the 256-MiB "
                         "last-level cache are counted, and the factor 2 is calibrated for coalesced 16-byte-per-lane reads only "
@@ -89,8 +100,8 @@ def roofline_block(pt, st, model):
                      "reference follows it to the depth cap: see segments_per_path against cpu_baseline.S)",
         "fp64_flop_issued_per_unit": flop_unit,
         "hbm_bytes_per_unit": hbm_unit,
-        "hbm_GBs": (traffic / launch_s / 1e9) if (traffic is not None and launch_s > 0) else None,
-        "hbm_frac_of_peak": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if (traffic is not None and launch_s > 0) else None,
+        "hbm_GBs": hbm_gbs,
+        "hbm_frac_of_peak": hbm_frac,
         "valu_busy_frac": model.get("valu_busy_frac"),
         "mean_active_lanes": model.get("mean_active_lanes"),
         "valu_insts_per_unit": model.get("valu_insts_per_unit"),
