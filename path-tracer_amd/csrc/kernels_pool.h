@@ -459,17 +459,20 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                 bool h0, h1, first0;
                 int32_t c0, c1;
                 if constexpr (QUANT) {
-                    const AccelNodeQ nq = ((const AccelNodeQ *)nodes)[node];
 #if PT_QUANT_F32
+                    const AccelNodeQWords nq = ((const AccelNodeQWords *)nodes)[node];
                     float t0, t1;
                     accel_boxes_qf(nq, qr, 0.000999f, closest_up, h0, h1, t0, t1); // (below the 0.001 of a render's rays)
+                    c0 = (int32_t)nq.b.z;
+                    c1 = (int32_t)nq.b.w;
 #else
+                    const AccelNodeQ nq = ((const AccelNodeQ *)nodes)[node];
                     double t0, t1;
                     accel_boxes_q(nq, qr, 0.001, closest, h0, h1, t0, t1);
-#endif
-                    first0 = t0 <= t1;
                     c0 = nq.child[0];
                     c1 = nq.child[1];
+#endif
+                    first0 = t0 <= t1;
                 } else {
                     double t0, t1;
                     const AccelNode &nd = nodes[node];
