@@ -1,6 +1,8 @@
 // Host-side SAH BVH builder for the fast-mode traversal (see accel.h).
 #include "accel.h"
 
+#include <limits>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -408,8 +410,10 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
         }
         out.prims.push_back(op);
     }
-    // Compact records, if the scene is plain spheres alone: untransformed, constant colour, one of the four surface
-    // materials, and sign bits free to carry the material kind.
+    // Compact records, if the scene is plain spheres alone: untransformed, one of the four surface materials, sign bits
+    // free to carry the material kind, and a colour that is either constant or a texture evaluated from the hit point
+    // alone (a checker: random_scene's ground). A textured sphere's record holds the texture's index in albedo[0] and a
+    // NaN in albedo[1] (a constant colour that qualifies is finite).
     out.spheres.clear();
     bool compact = !flat.has_medium;
     for (size_t k = 0; k < out.prims.size() && compact; ++k) {
@@ -418,15 +422,23 @@ bool build_accel(const FlatScene &flat, Accel &out, std::string &error) {
         const double param = lf.mat_kind == PT_M_LAMBERTIAN ? lf.emissive
                              : lf.mat_kind == PT_M_METAL    ? lf.fuzz
                              : lf.mat_kind == PT_M_DIELECTRIC ? lf.ref_idx : 0.0;
-        compact = op_kind(op.kind) == OP_SPHERE && lf.full_count == 0 && lf.texture < 0 && lf.mat_kind >= PT_M_LAMBERTIAN &&
+        const bool textured = lf.texture >= 0;
+        compact = op_kind(op.kind) == OP_SPHERE && lf.full_count == 0 && lf.mat_kind >= PT_M_LAMBERTIAN &&
                   lf.mat_kind <= PT_M_DIELECTRIC && std::isfinite(op.d[3]) && !std::signbit(op.d[3]) && std::isfinite(param) &&
-                  !std::signbit(param);
+                  !std::signbit(param) &&
+                  (textured ? (lf.tex_flags & (kLeafTexUv | kLeafTexNoise)) == 0
+                            : std::isfinite(lf.albedo[0]) && std::isfinite(lf.albedo[1]) && std::isfinite(lf.albedo[2]));
         if (!compact) break;
         const int code = lf.mat_kind - 1;
         DevSphere sp;
         for (int a = 0; a < 3; ++a) {
             sp.c[a] = op.d[a];
             sp.albedo[a] = lf.albedo[a];
+        }
+        if (textured) {
+            sp.albedo[0] = (double)lf.texture;
+            sp.albedo[1] = std::numeric_limits<double>::quiet_NaN();
+            sp.albedo[2] = 0.0;
         }
         sp.radius = (code & 1) ? -op.d[3] : op.d[3];
         sp.param = (code & 2) ? -param : param;

@@ -80,7 +80,7 @@ struct DevLeaf { // 192 bytes
 };
 static_assert(sizeof(DevLeaf) == 192, "DevLeaf must be 192 bytes");
 
-// The compact record of a scene made of plain spheres alone (no wrapper, constant texture): 64 bytes that serve BOTH
+// The compact record of a scene made of plain spheres alone (no wrapper; constant colours and checkers): 64 bytes that serve BOTH
 // the leaf test of the tree traversal and the shaded vertex, in the tree's leaf order, instead of a 64-byte DevOp for
 // the test and a 192-byte DevLeaf somewhere else in memory for the vertex. One million spheres: 64 MB beside 62 MB of
 // nodes, where ops + leaves + nodes were 318 MB (more than the 256-MB last-level cache holds). The material kind sits
@@ -91,7 +91,8 @@ static_assert(sizeof(DevLeaf) == 192, "DevLeaf must be 192 bytes");
 struct DevSphere { // 64 bytes
     double c[3];
     double radius;
-    double albedo[3]; // the constant texture's colour, or METAL's albedo
+    double albedo[3]; // the constant texture's colour, or METAL's albedo; {texture index, NaN, 0} for a texture evaluated
+                      // from the hit point alone (a checker)
     double param;
 };
 static_assert(sizeof(DevSphere) == 64, "DevSphere must be 64 bytes");

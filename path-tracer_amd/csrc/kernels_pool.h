@@ -17,6 +17,10 @@ struct PoolConsts {
     CameraDev cam;
     PassParams pp;
     AccelGrid grid; // of the 32-byte nodes, for the kernels that read those
+    // Where a ray starts in the 32-byte nodes: on `start_node`, with `start_push` on its stack when start_sp is 1. A small
+    // tree whose root holds a leaf (the scene-wide primitives) and the tree over the rest has its grid over the rest
+    // alone; the root's own boxes, which that grid cannot hold, are not tested: both children count as hit.
+    int32_t start_node, start_push; // (start_node < 0, a leaf: one stack entry)
 };
 // Puts a pass's constants where the pool kernels read them. They arrive as kernel arguments, i.e. with the launch packet:
 // a copy from pageable host memory costs the host a staging copy and a wait of its own per pass, which a realtime frame
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk_arg) {
     static_assert(!QUANT || SPH, "the 32-byte nodes are read by the variant for plain spheres only");
+    static_assert(!SPH || (TEX <= 1 && !MEDIA), "compact records: constant colours and checkers, no media");
     const uint32_t chunk = chunk_arg & 0x7fffffffu;
     const bool static_chunks = (chunk_arg >> 31) != 0u; // RT: one chunk per wave, dealt by wave index
     bool started = false;
@@ -337,9 +342,14 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
     QuantRay qr{o, o};
 #endif
     auto start_ray = [&]() { // (o, d) hold a new ray
+        int32_t first_node = 0;
+        sp = 0;
         if constexpr (QUANT) {
             const PoolConsts *pc = consts;
             asm volatile("" : "+s"(pc)); // keeps the loads in this block
+            first_node = pc->start_node;            // the root, or the leaf the root holds ...
+            stack[0][threadIdx.x] = pc->start_push; // ... with the rest of the tree behind it
+            sp = first_node < 0 ? 1 : 0;
 #if PT_QUANT_F32
             qr = quant_ray_f(pc->grid, o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
             closest_up = __builtin_inff();
@@ -351,10 +361,9 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
         }
         closest = kF64Max;
         best = -1;
-        sp = 0;
         // rays with a NaN or infinite component are not traced (see k_extend_accel)
         const double probe = (o.x + o.y + o.z) + (d.x + d.y + d.z);
-        node = (probe == probe && fabs(probe) <= kF64Max) ? 0 : kDone;
+        node = (probe == probe && fabs(probe) <= kF64Max) ? first_node : kDone;
     };
     // pixel of the h-th path id of the pass
     auto pixel_of = [&](const PassParams &pp, uint32_t h, uint32_t &i, uint32_t &jy, uint32_t &smp) -> uint64_t {
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     lf.axis = 0;
                     lf.mat_kind = 1 + (int32_t)((uint32_t)__double2hiint(sp.radius) >> 31) +
                                   2 * (int32_t)((uint32_t)__double2hiint(sp.param) >> 31);
-                    lf.texture = -1;
+                    lf.texture = (TEX != 0 && sp.albedo[1] != sp.albedo[1]) ? (int32_t)sp.albedo[0] : -1; // (see DevSphere)
                     lf.full_start = lf.full_count = 0;
                     lf.material = lf.op = lf.prim[0] = 0;
                     lf.tex_flags = 0;

@@ -186,6 +186,7 @@ struct pt_ctx {
     bool compact_spheres = true;     // use them (PT_CFG_FAT_RECORDS turns them off, for A/B runs)
     bool quant_pool = true;          // the sphere tree pool reads the 32-byte nodes where they exist (PT_CFG_WIDE_NODES turns that off, for A/B runs)
     AccelGrid accel_grid_q{};
+    int32_t accel_q_start[2] = {0, 0}; // where rays start in the 32-byte nodes: node (the root, or the leaf it holds) and the node pushed behind it
     int32_t n_accel_nodes = 0;
     std::vector<std::pair<int32_t, int32_t>> accel_levels; // refit order (deepest level first): index ranges of d_accel_levels, or node id ranges when that is null
     int accel_depth = 0;
@@ -416,7 +417,7 @@ void launch_extend_xfm(pt_ctx *ctx, int grid, const Queue &q, const ExtendArgs &
                            (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a);
     } else if (!X && ctx->accel_ok && a.counters == nullptr && ctx->accel_pool && !(ctx->accel_pool_from > a.depth && a.key_mode == 0)) {
         grid = std::min(grid, ctx->n_cu * (MEDIA ? 4 : 5) * (int)ctx->accel_grid); // what is resident at once
-        if (ctx->d_accel_nodes_q)
+        if (ctx->d_accel_nodes_q && ctx->n_accel_nodes >= kAccelQuantFrom) // (a smaller tree's grid may leave out the root's boxes)
             hipLaunchKernelGGL((k_extend_accel_pool<MEDIA, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q, ctx->view,
                                (const AccelNode *)ctx->d_accel_nodes, (const DevOp *)ctx->d_accel_prims, a,
                                ctx->accel_refill | (ctx->accel_inner << 8), (const AccelNodeQ *)ctx->d_accel_nodes_q, ctx->accel_grid_q);
@@ -529,7 +530,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
             if (hipError_t e = counted_malloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp, ctx->accel_grid_q}, (PoolConsts *)ctx->d_pool_consts);
+        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1]}, (PoolConsts *)ctx->d_pool_consts);
         return hipGetLastError();
     };
     if (pool || tree || xpool) {
@@ -615,7 +616,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     }
     if (tree) {
         const uint32_t tiles = (n + 63u) / 64u;
-        const bool spheres = ctx->d_accel_spheres && ctx->compact_spheres && ctx->tex == 0 && !ctx->view.has_medium;
+        const bool spheres = ctx->d_accel_spheres && ctx->compact_spheres && ctx->tex <= 1 && !ctx->view.has_medium;
         const uint32_t resident = (uint32_t)ctx->n_cu * (ctx->tex == 2 ? PT_TREE_UV_WAVES : spheres ? PT_SPH_WAVES : PT_SHADE_WAVES) * ctx->pool_grid;
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         const uint32_t waves = grid * kWavesPerBlock;
@@ -662,11 +663,17 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                    ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
             };
             const bool quant = ctx->d_accel_nodes_q != nullptr && ctx->quant_pool;
-            if (quant) {
-                if (realtime) launch_sph_q(k_tree_pool<0, false, true, true, true>);
-                else launch_sph_q(k_tree_pool<0, false, false, true, true>);
-            } else if (realtime) launch_sph(k_tree_pool<0, false, true, true>);
-            else launch_sph(k_tree_pool<0, false, false, true>);
+            if (ctx->tex == 0) {
+                if (quant) {
+                    if (realtime) launch_sph_q(k_tree_pool<0, false, true, true, true>);
+                    else launch_sph_q(k_tree_pool<0, false, false, true, true>);
+                } else if (realtime) launch_sph(k_tree_pool<0, false, true, true>);
+                else launch_sph(k_tree_pool<0, false, false, true>);
+            } else if (quant) {
+                if (realtime) launch_sph_q(k_tree_pool<1, false, true, true, true>);
+                else launch_sph_q(k_tree_pool<1, false, false, true, true>);
+            } else if (realtime) launch_sph(k_tree_pool<1, false, true, true>);
+            else launch_sph(k_tree_pool<1, false, false, true>);
         } else
         with_tex(ctx->tex, [&](auto T) {
             constexpr int kTex = decltype(T)::value;
@@ -1579,14 +1586,22 @@ static int quantise_nodes(pt_ctx *ctx) {
         ctx->d_accel_nodes_q = nullptr;
     }
     const int32_t n = ctx->n_accel_nodes;
-    if (n < kAccelQuantFrom) return PT_OK;
+    // big trees, and any tree over compact sphere records (their pass kernel has the registers for the quantised ray)
+    if (n < kAccelQuantFrom && ctx->d_accel_spheres == nullptr) return PT_OK;
     AccelNode root;
     HIP_TRY(ctx, hipMemcpyAsync(&root, ctx->d_accel_nodes, sizeof(root), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // A small tree whose root holds a leaf (the scene-wide primitives, csrc/accel.cpp) and the tree over the rest: the grid
+    // spans the rest alone, so that a ground sphere of radius 1000 does not set the step for spheres of radius 0.2; rays
+    // start on that leaf with the rest pushed, and the root's own boxes, which this grid cannot hold, are never read.
+    // (Big trees keep the grid over everything: the extend kernel reads them too, from the root.)
+    const bool rest_only = n < kAccelQuantFrom && root.child[0] < 0 && root.child[1] >= 0;
+    ctx->accel_q_start[0] = rest_only ? root.child[0] : 0;
+    ctx->accel_q_start[1] = rest_only ? root.child[1] : 0;
     AccelGrid g;
     for (int a = 0; a < 3; ++a) {
-        const double lo = std::min((double)root.lo[0][a], (double)root.lo[1][a]);
-        const double hi = std::max((double)root.hi[0][a], (double)root.hi[1][a]);
+        const double lo = rest_only ? (double)root.lo[1][a] : std::min((double)root.lo[0][a], (double)root.lo[1][a]);
+        const double hi = rest_only ? (double)root.hi[1][a] : std::max((double)root.hi[0][a], (double)root.hi[1][a]);
         if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return PT_OK; // nothing to quantise against
         g.gmin[a] = lo;
         g.cell[a] = hi > lo ? (hi - lo) / 65535.0 * (1.0 + 1e-12) : 1.0;
