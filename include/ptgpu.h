@@ -183,10 +183,11 @@ typedef struct pt_tuning {
     uint32_t pool_chunk;           /* pool kernels: path ids a wave takes from the pass's counter at a time (64..2^20) */
     uint32_t pool_grid;            /* pool kernels: workgroups per resident slot (1..256) */
     uint32_t tree_refill, tree_inner, tree_shade; /* tree pool thresholds in lanes (1..64): refill at (default 16,
-                                                     big trees of plain spheres 4) / stay on inner nodes while
-                                                     (default 16, trees of 32 768 nodes and more 24, of plain
-                                                     spheres 28, realtime frames 4) / shade when this many lanes (default 32,
-                                                     realtime frames 48) ... */
+                                                     plain spheres alone: small trees 24, big trees 4) / stay on
+                                                     inner nodes while (default 16, trees of 32 768 nodes and more
+                                                     24; plain spheres alone: small trees 8, big trees 28; realtime
+                                                     frames 4) / shade when this many lanes (default 32, small
+                                                     trees of plain spheres 44, realtime frames 48) ... */
     uint32_t tree_trav_plus1;      /* ... or at most this many minus one (1..65) still traverse */
     uint32_t accel_form;           /* extend stage over the SAH tree: 1 = a ray per thread, 2 = refilled lane pool */
     uint32_t accel_refill, accel_inner, accel_grid; /* lane pool thresholds (1..64, 1..65) and workgroups per slot (1..8) */

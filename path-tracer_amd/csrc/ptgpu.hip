@@ -633,11 +633,16 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         // The variant for plain spheres on a big tree (32-byte nodes, a vertex of a few hundred instructions) takes new paths
         // as soon as four lanes are free and leaves its inner nodes at 28 lanes (one million spheres: 710 -> 773 Mpaths/s
         // against 16 / 24; refill at 1 .. 6 within 0.5 %, inner 20 / 32 / 40: 742 / 763 / 699).
+        // A small tree of compact sphere records (random_scene): a vertex is cheap next to a round of the traversal, so
+        // shading waits for 44 ready lanes, the lanes on inner nodes step on down to 8 of them, and new paths come in
+        // batches of 24 (7 000 -> 7 450 Mpaths/s against 32 / 16 / 16; each of the three within 1 % of its neighbours).
         const bool big = ctx->n_accel_nodes >= kAccelQuantFrom;
+        const bool small_spheres = spheres && !big && !realtime;
         const uint32_t inner_min = ctx->tree_inner_set ? ctx->tree_tuning[1]
-                                   : realtime ? 4u : (big ? (spheres ? 28u : 24u) : ctx->tree_tuning[1]);
-        const uint32_t shade_min = ctx->tree_shade_set ? ctx->tree_tuning[2] : (realtime ? 48u : ctx->tree_tuning[2]);
-        const uint32_t refill_at = ctx->tree_refill_set ? ctx->tree_tuning[0] : ((big && spheres && !realtime) ? 4u : ctx->tree_tuning[0]);
+                                   : realtime ? 4u : (big ? (spheres ? 28u : 24u) : small_spheres ? 8u : ctx->tree_tuning[1]);
+        const uint32_t shade_min = ctx->tree_shade_set ? ctx->tree_tuning[2] : (realtime ? 48u : small_spheres ? 44u : ctx->tree_tuning[2]);
+        const uint32_t refill_at = ctx->tree_refill_set ? ctx->tree_tuning[0]
+                                   : ((big && spheres && !realtime) ? 4u : small_spheres ? 24u : ctx->tree_tuning[0]);
         const uint32_t tuning = refill_at | (inner_min << 8) | (shade_min << 16) | (ctx->tree_tuning[3] << 24);
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, mark());
