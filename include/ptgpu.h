@@ -319,6 +319,13 @@ int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double
 
 int pt_stats_get(pt_ctx *ctx, pt_stats *out);
 int pt_stats_reset(pt_ctx *ctx);
+/* Which records the most recent pass read (a diagnostic, for tests and A/B runs; no reference counterpart): a set of
+ * PT_RECORDS_* bits, or a negative pt_error. */
+enum pt_pass_records {
+    PT_RECORDS_COMPACT_SPHERES = 1, /* the 64-byte sphere records that serve leaf test and vertex (scenes of plain spheres) */
+    PT_RECORDS_NODES32 = 2          /* the 32-byte tree nodes with f32 slab tests */
+};
+int pt_last_pass_records(pt_ctx *ctx);
 
 /* The HIP stream every kernel of this context is launched on (hipStream_t). */
 void *pt_stream(pt_ctx *ctx);

@@ -45,6 +45,8 @@ PT_CFG_COUNT_TRAVERSAL = 2
 PT_CFG_EXACT = 4
 PT_CFG_FAT_RECORDS = 8
 PT_CFG_WIDE_NODES = 32
+PT_RECORDS_COMPACT_SPHERES = 1
+PT_RECORDS_NODES32 = 2
 PT_CFG_COUNT_ACCEL = 16
 
 # pt_hitable_kind
@@ -235,7 +237,7 @@ assert RAY_DTYPE.itemsize == 56 and HIT_DTYPE.itemsize == 80
 # Every symbol include/ptgpu.h declares.
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_scene_upload", "pt_camera_set", "pt_render", "pt_accum_reset",
-    "pt_readback", "pt_image_device_ptr", "pt_image_bind", "pt_intersect", "pt_stats_get", "pt_stats_reset",
+    "pt_readback", "pt_image_device_ptr", "pt_image_bind", "pt_intersect", "pt_stats_get", "pt_stats_reset", "pt_last_pass_records",
     "pt_stream", "pt_intersect_device", "pt_scene_build_named", "pt_scene_free", "pt_scene_get_desc", "pt_scene_new",
     "pt_scene_texture_constant", "pt_scene_texture_checker", "pt_scene_texture_noise", "pt_scene_texture_image",
     "pt_scene_material_lambertian", "pt_scene_material_diffuse_light", "pt_scene_material_metal",
@@ -277,6 +279,7 @@ _sig("pt_image_bind", C.c_int, _vp, _vp, C.c_uint32, C.c_uint32)
 _sig("pt_intersect", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, _vp)
 _sig("pt_stats_get", C.c_int, _vp, C.POINTER(Stats))
 _sig("pt_stats_reset", C.c_int, _vp)
+_sig("pt_last_pass_records", C.c_int, _vp)
 _sig("pt_stream", _vp, _vp)
 _sig("pt_intersect_device", C.c_int, _vp, _vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_int, _d3)
 _sig("pt_scene_build_named", C.c_int, C.c_char_p, C.c_double, C.c_uint64, C.c_int64, C.POINTER(_vp), C.POINTER(Camera))
@@ -695,6 +698,13 @@ class Context:
 
     def stats_reset(self):
         self._check(lib.pt_stats_reset(self._h), "pt_stats_reset")
+
+    def last_pass_records(self) -> int:
+        """PT_RECORDS_* bits of the most recent pass (pt_last_pass_records)."""
+        rc = lib.pt_last_pass_records(self._h)
+        if rc < 0:
+            self._check(rc, "pt_last_pass_records")
+        return rc
 
 
 def group_unique_id() -> bytes:

@@ -186,6 +186,7 @@ struct pt_ctx {
     bool compact_spheres = true;     // use them (PT_CFG_FAT_RECORDS turns them off, for A/B runs)
     bool quant_pool = true;          // the sphere tree pool reads the 32-byte nodes where they exist (PT_CFG_WIDE_NODES turns that off, for A/B runs)
     AccelGrid accel_grid_q{};
+    int last_pass_records = 0;       // PT_RECORDS_* of the most recent pass
     int32_t accel_q_start[2] = {0, 0}; // where rays start in the 32-byte nodes: node (the root, or the leaf it holds) and the node pushed behind it
     int32_t n_accel_nodes = 0;
     std::vector<std::pair<int32_t, int32_t>> accel_levels; // refit order (deepest level first): index ranges of d_accel_levels, or node id ranges when that is null
@@ -614,6 +615,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                   ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill | static_bit, chunk);
         HIP_TRY(ctx, mark());
     }
+    ctx->last_pass_records = 0;
     if (tree) {
         const uint32_t tiles = (n + 63u) / 64u;
         const bool spheres = ctx->d_accel_spheres && ctx->compact_spheres && ctx->tex <= 1 && !ctx->view.has_medium;
@@ -668,6 +670,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
                                    ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
             };
             const bool quant = ctx->d_accel_nodes_q != nullptr && ctx->quant_pool;
+            ctx->last_pass_records = PT_RECORDS_COMPACT_SPHERES | (quant ? PT_RECORDS_NODES32 : 0);
             if (ctx->tex == 0) {
                 if (quant) {
                     if (realtime) launch_sph_q(k_tree_pool<0, false, true, true, true>);
@@ -1743,6 +1746,11 @@ int pt_scene_build_device(pt_ctx *ctx, double time0, double time1) {
     if ((rc = refit_levels(ctx, time0, time1)) != PT_OK) return rc;
     ctx->accel_ok = true;
     return PT_OK;
+}
+
+int pt_last_pass_records(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    return ctx->last_pass_records;
 }
 
 int pt_stats_get(pt_ctx *ctx, pt_stats *out) {

@@ -191,22 +191,27 @@ def test_compact_sphere_records_give_the_same_image(case):
     """A scene of plain spheres alone is traced through 64-byte records that serve the leaf test and the vertex alike
     (k_tree_pool<.., SPH>); PT_CFG_FAT_RECORDS sends the same scene through the general primitive and leaf records.
     Same arithmetic on the same values: every f32 channel identical, NaN pixels included, offline and in realtime
-    frames, also after the tree has been rebuilt on the device (which reorders the records). A scene that does not
-    qualify (a sphere under a Translate, a non-constant texture) takes the general records either way."""
+    frames, also after the tree has been rebuilt on the device (which reorders the records). A checker colour (a texture
+    evaluated from the hit point alone) travels in the record as a texture index; a scene that does not qualify (a sphere
+    under a Translate) takes the general records either way. Trees of any size over compact records are read as 32-byte
+    nodes with f32 slab tests (PT_CFG_WIDE_NODES: the 64-byte nodes and their f64 tests)."""
     if case == "cloud":
         scene, w, h, spp, depth = ptgpu.Scene.named("sphere_cloud", 16 / 9, param=200000), 256, 144, 2, 10
     else:
         scene = _sphere_scene(300, translated=case == "translated", textured=case == "textured")
         w, h, spp, depth = 96, 64, 4, 12
     images = {}
-    forms = [("compact", 0), ("fat", ptgpu.PT_CFG_FAT_RECORDS)]
-    if case == "cloud":  # a tree big enough for the 32-byte nodes: the compact records over either node form
-        forms.append(("wide_nodes", ptgpu.PT_CFG_WIDE_NODES))
+    forms = [("compact", 0), ("fat", ptgpu.PT_CFG_FAT_RECORDS), ("wide_nodes", ptgpu.PT_CFG_WIDE_NODES)]
     for label, flags in forms:
         ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 18, flags=flags)
         ctx.upload(scene)
         ctx.render(w, h, spp, depth)
         assert int(ctx.stats().last_pass_form) == ptgpu.PT_PASS_TREE_POOL
+        # which records the pass read: the compact ones unless the flag or the scene rules them out (a checker colour does
+        # not), and with them the 32-byte nodes unless that flag is set
+        want = 0 if (label == "fat" or case == "translated") else ptgpu.PT_RECORDS_COMPACT_SPHERES | (
+            0 if label == "wide_nodes" else ptgpu.PT_RECORDS_NODES32)
+        assert ctx.last_pass_records() == want, (label, case)
         offline = ctx.readback()
         ctx.reset()
         for frame in range(3):
@@ -227,6 +232,21 @@ def test_compact_sphere_records_give_the_same_image(case):
         ref, _ = ob.render(scene.desc(), scene.camera, w, h, spp, depth, seed=0x5EED0001, threads=4)
         close, rel_rmse, nan_same = _compare(images["compact"][0], ref)
         assert nan_same >= 0.99 and close >= 0.98, (close, rel_rmse, nan_same)
+
+
+def test_sphere_recipes_take_the_compact_records():
+    """random_scene (checker ground, a scene-wide leaf at the root) and the sphere cloud are traced through the compact
+    records over 32-byte nodes, offline and in realtime frames; the final scene (boxes, media, wrappers) is not."""
+    for name, param, want in (("random_scene", 0, ptgpu.PT_RECORDS_COMPACT_SPHERES | ptgpu.PT_RECORDS_NODES32),
+                              ("sphere_cloud", 50000, ptgpu.PT_RECORDS_COMPACT_SPHERES | ptgpu.PT_RECORDS_NODES32),
+                              ("final_book_two", 0, 0)):
+        ctx = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 18)
+        ctx.upload(ptgpu.Scene.named(name, 1.5, param=param))
+        ctx.render(96, 64, 2, 10)
+        assert int(ctx.stats().last_pass_form) == ptgpu.PT_PASS_TREE_POOL and ctx.last_pass_records() == want, name
+        ctx.render(96, 64, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=1)
+        assert ctx.last_pass_records() == want, name
+        ctx.close()
 
 
 def test_tree_traversal_counters():
