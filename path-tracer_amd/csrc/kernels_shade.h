@@ -151,7 +151,16 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     // (src/material.rs:10-19) are the same construction: a basis about an axis, z from the second
                     // draw, the azimuth from the first. The lanes of both run it together instead of one group after
                     // the other; what differs is selected per lane.
-                    const DevLight &l = sv.lights[which];
+                    // The light shape a lane aims at comes through the scalar cache: the list is a handful of records,
+                    // so each is read once for the wave (a uniform address) and the lanes that drew it keep it. A load
+                    // at the lane's own index is a vector load whose round trip sits right in front of the sampling.
+                    DevLight l = load_light_uniform(sv.lights);
+                    for (int k = 1; k < sv.n_lights; ++k) {
+                        if (__ballot(to_light && which == k)) {
+                            const DevLight lk = load_light_uniform(sv.lights + k);
+                            if (which == k) l = lk;
+                        }
+                    }
                     const bool to_sphere = to_light && l.kind == LIGHT_SPHERE;
                     if (to_sphere || (!to_light && lambert)) {
                         g.n += 2;

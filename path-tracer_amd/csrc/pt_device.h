@@ -788,16 +788,63 @@ template <bool X> PT_DEV bool checker_is_odd(D3 p) {
         return (odd == 1.0 || odd == 3.0) && !any_zero;
     }
 }
+// Records read at a wave-uniform address come through the scalar cache into scalar registers (the constant address
+// space is how the compiler is told that it may do so; the scene's tables are never written while a kernel runs).
+PT_DEV pt_texture load_texture_uniform(const pt_texture *p) {
+    const pt_texture __attribute__((address_space(4))) *cp = (const pt_texture __attribute__((address_space(4))) *)p;
+    pt_texture t;
+    t.kind = cp->kind;
+    t.even = cp->even;
+    t.odd = cp->odd;
+    t.width = cp->width;
+    t.height = cp->height;
+    t.reserved = 0;
+    t.texel_offset = cp->texel_offset;
+    t.colour[0] = cp->colour[0];
+    t.colour[1] = cp->colour[1];
+    t.colour[2] = cp->colour[2];
+    t.scale = cp->scale;
+    return t;
+}
+PT_DEV DevLight load_light_uniform(const DevLight *p) {
+    const DevLight __attribute__((address_space(4))) *cp = (const DevLight __attribute__((address_space(4))) *)p;
+    DevLight l;
+    l.kind = cp->kind;
+    l.axis = cp->axis;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) l.d[k] = cp->d[k];
+    return l;
+}
 // `turbulence`: perlin_turb(p, 7) already evaluated for this hit (by the whole wave, see wave_turb7), or null.
 template <bool X, int TEX>
 PT_DEV D3 texture_value(const SceneView &sv, int tex, double u, double v, D3 p, const double *turbulence = nullptr) {
     if constexpr (TEX == 0) return d3(0.0, 0.0, 0.0);
-    const pt_texture *t = &sv.textures[tex];
-    if (t->kind == PT_T_CHECKER) { // the cell is the same at every level of nested checkers
+    // Texture records come through the scalar cache: the calling lanes hold a few distinct indices (one checker and
+    // its two colours, a noise and an image texture), so the wave reads one index at a time at a uniform address and
+    // the lanes that asked for it keep the record. Read at each lane's own index, a checker is three dependent vector
+    // loads in front of the vertex's sampling.
+    auto fetch = [&](int index, bool want, pt_texture &rec) {
+        bool pending = want;
+        for (;;) {
+            const unsigned long long left = __ballot(pending);
+            if (!left) break;
+            const int k = __builtin_amdgcn_readlane(index, __ffsll((long long)left) - 1); // the first unserved lane's index
+            const pt_texture rk = load_texture_uniform(sv.textures + k);
+            if (pending && index == k) {
+                rec = rk;
+                pending = false;
+            }
+        }
+    };
+    pt_texture rec;
+    fetch(tex, true, rec);
+    if (__ballot(rec.kind == PT_T_CHECKER)) { // the cell is the same at every level of nested checkers
         const bool odd = checker_is_odd<X>(p);
 #pragma unroll 1
-        for (int guard = 0; guard < 16 && t->kind == PT_T_CHECKER; ++guard) t = &sv.textures[odd ? t->odd : t->even];
+        for (int guard = 0; guard < 16 && __ballot(rec.kind == PT_T_CHECKER); ++guard)
+            fetch(odd ? rec.odd : rec.even, rec.kind == PT_T_CHECKER, rec);
     }
+    const pt_texture *t = &rec;
     if (t->kind == PT_T_CONSTANT) return d3(t->colour[0], t->colour[1], t->colour[2]);
     if (TEX == 2 && t->kind == PT_T_NOISE) {
         double noise = t->scale * p.z + 10.0 * (turbulence ? *turbulence : perlin_turb(sv.perlin, p, 7));
@@ -989,7 +1036,8 @@ template <bool X> PT_DEV D3 light_random(const DevLight &l, uint32_t u1, uint32_
 template <bool X> PT_DEV double lights_pdf_value(const SceneView &sv, D3 origin, D3 direction, double len2, double inv_len) {
     double weight = 1.0 / (double)sv.n_lights;
     double sum = 0.0;
-    for (int k = 0; k < sv.n_lights; ++k) sum += weight * light_pdf_value<X>(sv.lights[k], origin, direction, len2, inv_len);
+    for (int k = 0; k < sv.n_lights; ++k) // (k is the same in every lane: the record comes through the scalar cache)
+        sum += weight * light_pdf_value<X>(load_light_uniform(sv.lights + k), origin, direction, len2, inv_len);
     return sum;
 }
 
