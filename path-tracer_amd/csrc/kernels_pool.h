@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
                 asm volatile("" : "+s"(pc)); // keeps the loads below in this block
                 uint32_t m, id;
                 if constexpr (RT) {
-                    const PassParams ppr = pc->pp;
+                    const PassParams ppr = load_uniform(&pc->pp);
                     while (live_n < 64u) { // skip draws of the next 64 ids; the survivors join the list (at most 64 + 64)
                         next_chunk();
                         if (cur >= end) break;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
                     cur += m;
                 }
                 // the next (up to) 64 camera samples, one per lane, parked in LDS
-                const CameraDev cam = pc->cam;
-                const PassParams pp = pc->pp;
+                const CameraDev cam = load_uniform(&pc->cam);
+                const PassParams pp = load_uniform(&pc->pp);
                 const bool fresh = lane < m;
                 uint32_t i = 0, jy = 0, smp = 0;
                 uint64_t pixel = 0;
@@ -347,14 +347,14 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
         if constexpr (QUANT) {
             const PoolConsts *pc = consts;
             asm volatile("" : "+s"(pc)); // keeps the loads in this block
-            first_node = pc->start_node;            // the root, or the leaf the root holds ...
-            stack[0][threadIdx.x] = pc->start_push; // ... with the rest of the tree behind it
+            first_node = load_uniform(&pc->start_node);            // the root, or the leaf the root holds ...
+            stack[0][threadIdx.x] = load_uniform(&pc->start_push); // ... with the rest of the tree behind it
             sp = first_node < 0 ? 1 : 0;
 #if PT_QUANT_F32
-            qr = quant_ray_f(pc->grid, o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
+            qr = quant_ray_f(load_uniform(&pc->grid), o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
             closest_up = __builtin_inff();
 #else
-            qr = quant_ray(pc->grid, o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
+            qr = quant_ray(load_uniform(&pc->grid), o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
 #endif
         } else {
             inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
@@ -377,8 +377,8 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
     auto take_path = [&](uint32_t h) {
         const PoolConsts *pc = consts;
         asm volatile("" : "+s"(pc)); // keeps the loads below in this block
-        const CameraDev cam = pc->cam;
-        const PassParams pp = pc->pp;
+        const CameraDev cam = load_uniform(&pc->cam);
+        const PassParams pp = load_uniform(&pc->pp);
         pid = h;
         uint32_t i, jy, smp;
         const uint64_t pixel = pixel_of(pp, h, i, jy, smp);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     }
                     const PoolConsts *pc = consts;
                     asm volatile("" : "+s"(pc));
-                    const PassParams pp = pc->pp;
+                    const PassParams pp = load_uniform(&pc->pp);
                     const uint32_t h = cur + lane;
                     bool alive = false;
                     if (h < end) {

@@ -790,6 +790,16 @@ template <bool X> PT_DEV bool checker_is_odd(D3 p) {
 }
 // Records read at a wave-uniform address come through the scalar cache into scalar registers (the constant address
 // space is how the compiler is told that it may do so; the scene's tables are never written while a kernel runs).
+// Any trivially copyable record, word by word (the compiler merges the words into wide scalar loads).
+template <class T> PT_DEV T load_uniform(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "copied word by word");
+    const uint32_t __attribute__((address_space(4))) *src = (const uint32_t __attribute__((address_space(4))) *)p;
+    T out;
+    uint32_t *dst = (uint32_t *)&out;
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) dst[k] = src[k];
+    return out;
+}
 PT_DEV pt_texture load_texture_uniform(const pt_texture *p) {
     const pt_texture __attribute__((address_space(4))) *cp = (const pt_texture __attribute__((address_space(4))) *)p;
     pt_texture t;
