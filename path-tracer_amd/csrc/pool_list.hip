@@ -1,9 +1,10 @@
 // The fast-mode path pool over primitive lists without media, k_path_pool<TEX, 1, false> (kernels_pool.h): the kernel that
-// traces the Cornell box. It is the one kernel of the library whose time is the issue rate of the FP64 pipe at a register
-// budget it just fits (128 VGPRs, a few spills), and it is compiled here, apart from the others, under the scheduling
-// strategy that keeps register pressure lowest (the Makefile passes -mllvm -amdgpu-sched-strategy=iterative-minreg for
-// this file): +2 to +3 % on the Cornell box. The same flag costs the tree pool 3 to 34 %, exact mode 2 % and the variant with
-// media inside 2 %, which is why those stay in ptgpu.hip under the default scheduler. Same sources, same arithmetic (-ffp-contract=off in both).
+// traces the Cornell box, in a translation unit of its own so that its scheduling strategy can be chosen apart from the
+// other kernels' (the Makefile's POOL_LIST_FLAGS). While the kernel read its pass constants by vector loads it sat a few
+// spills above its 128 registers, and -mllvm -amdgpu-sched-strategy=iterative-minreg was worth +2 to +3 % (the same flag
+// costs the tree pool 3 to 34 %); with those constants in scalar registers it has no scratch under any strategy, and the
+// default scheduler is the fastest again (+1 % over iterative-minreg, max-ilp between the two). Same sources, same
+// arithmetic (-ffp-contract=off in both).
 #include <hip/hip_runtime.h>
 
 #include "accel.h"

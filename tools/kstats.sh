@@ -4,8 +4,8 @@ set -e
 cd "$(dirname "$0")/.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function ${KFLAGS} -Iinclude -Ipath-tracer_amd/csrc --cuda-device-only -S"
 /opt/rocm/bin/hipcc $FLAGS -o /tmp/ptgpu_k1.s path-tracer_amd/csrc/ptgpu.hip 2>/dev/null
-# the list path pool is a translation unit of its own, with its own scheduler flag (path-tracer_amd/Makefile)
-/opt/rocm/bin/hipcc $FLAGS ${POOL_LIST_FLAGS--mllvm -amdgpu-sched-strategy=iterative-minreg} -o /tmp/ptgpu_k2.s path-tracer_amd/csrc/pool_list.hip 2>/dev/null
+# the list path pool is a translation unit of its own (scheduler flags of its own: POOL_LIST_FLAGS of path-tracer_amd/Makefile)
+/opt/rocm/bin/hipcc $FLAGS ${POOL_LIST_FLAGS} -o /tmp/ptgpu_k2.s path-tracer_amd/csrc/pool_list.hip 2>/dev/null
 cat /tmp/ptgpu_k1.s /tmp/ptgpu_k2.s > /tmp/ptgpu_k.s
 python3 - "$1" <<'PY'
 import re, sys, subprocess, collections
