@@ -37,6 +37,19 @@ __device__ __forceinline__ long long *shade_clock() {
 #define PT_SHADE_TICK(k)
 #endif
 
+// The light shape each calling lane aims at (`which`, for the lanes that `want` one): the list is a handful of records, so
+// each is read once for the wave at a uniform address and the lanes that drew it keep it.
+__device__ __forceinline__ DevLight wave_light(const SceneView &sv, int which, bool want) {
+    DevLight l = load_light_uniform(sv.lights);
+    for (int k = 1; k < sv.n_lights; ++k) {
+        if (__ballot(want && which == k)) {
+            const DevLight lk = load_light_uniform(sv.lights + k);
+            if (which == k) l = lk;
+        }
+    }
+    return l;
+}
+
 // One path vertex: the body of `color` (src/trace.rs:198-234) for a ray whose closest hit is (ht, id), id < 0 for a
 // miss. `lf` is the hit primitive's leaf record (fields are fetched where they are used; any record when id < 0).
 // Adds the vertex's radiance to the path's accumulator and, if the path goes on, returns true with the next ray,
@@ -144,7 +157,8 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 D3 dir;
                 PT_SHADE_TICK(5)
                 if constexpr (X) {
-                    if (to_light) dir = light_random<X>(sv.lights[which], u1, u2, g, rec.p);
+                    const DevLight l = wave_light(sv, which, to_light);
+                    if (to_light) dir = light_random<X>(l, u1, u2, g, rec.p);
                     else dir = lambert ? onb_local(uvw, random_cosine_direction<X>(u1, u2, g)) : iso_dir;
                 } else {
                     // The cone towards a sphere light (src/sphere.rs:16-25,96-101) and the cosine lobe about the normal
@@ -154,13 +168,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                     // The light shape a lane aims at comes through the scalar cache: the list is a handful of records,
                     // so each is read once for the wave (a uniform address) and the lanes that drew it keep it. A load
                     // at the lane's own index is a vector load whose round trip sits right in front of the sampling.
-                    DevLight l = load_light_uniform(sv.lights);
-                    for (int k = 1; k < sv.n_lights; ++k) {
-                        if (__ballot(to_light && which == k)) {
-                            const DevLight lk = load_light_uniform(sv.lights + k);
-                            if (which == k) l = lk;
-                        }
-                    }
+                    const DevLight l = wave_light(sv, which, to_light);
                     const bool to_sphere = to_light && l.kind == LIGHT_SPHERE;
                     if (to_sphere || (!to_light && lambert)) {
                         g.n += 2;
