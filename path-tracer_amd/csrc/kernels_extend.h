@@ -190,7 +190,7 @@ __device__ __forceinline__ void extend_scan_walk(const SceneView &sv, D3 wo, D3 
             bool hit;
             if (MEDIA && kind == OP_MEDIUM) {
                 if (count && mine) my_prims += 2;
-                hit = medium_hit<X>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
+                hit = medium_hit<X, false, true>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t); // (the op is the wave's)
             } else {
                 if (count && mine) my_prims += (kind == OP_BOXPRIM) ? 6 : 1;
                 hit = prim_hit<X>(sv, op, o, d, inv, time, t_min, closest, t, sub);
@@ -299,7 +299,7 @@ template <bool MEDIA> struct ListWalk {
             hit = sphere_pred(d3(op.d[0], op.d[1], op.d[2]), op.d[3], po, pd, dd, inv_dd, t_min, closest, t, sub);
         else if (kind == OP_BOXPRIM) hit = box_pred(op.d, po, pinv, t_min, closest, t, sub);
         else if (MEDIA && kind == OP_MEDIUM)
-            hit = medium_hit<false>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t);
+            hit = medium_hit<false, false, true>(sv, op, o, d, inv, time, t_min, closest, pkey, depth, t); // (the op is the wave's)
         else hit = prim_hit_framed<false>(sv, op, po, pd, pinv, time, t_min, closest, t, sub);
         closest = hit ? t : closest;
         best = hit ? (op.leaf | (sub << 28)) : best;

@@ -265,6 +265,19 @@ struct SceneView {
     int32_t zero_can_turn_nan;
 };
 
+// Records read at a wave-uniform address come through the scalar cache into scalar registers (the constant address
+// space is how the compiler is told that it may do so; the scene's tables are never written while a kernel runs).
+// Any trivially copyable record, word by word (the compiler merges the words into wide scalar loads).
+template <class T> PT_DEV T load_uniform(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "copied word by word");
+    const uint32_t __attribute__((address_space(4))) *src = (const uint32_t __attribute__((address_space(4))) *)p;
+    T out;
+    uint32_t *dst = (uint32_t *)&out;
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) dst[k] = src[k];
+    return out;
+}
+
 // ------------------------------------------------------------ transforms --
 // Ray into a wrapper's child space: Translate::hit (src/hitable.rs:124), then RotateY::hit (204-206, via 182-187).
 template <bool X> PT_DEV void xform_ray(const DevXform &x, D3 &o, D3 &d) {
@@ -556,15 +569,26 @@ PT_DEV bool boundary_hit(const SceneView &sv, int32_t first, int32_t end, D3 o, 
 
 // ConstantMedium::hit (src/volume.rs:24-65). The ray is in the medium's frame once the op's chain is applied.
 // GENERAL: the boundary may be a sub-stream of several ops (op.d[1] of them); otherwise it is one primitive op.
-template <bool X, bool GENERAL = false>
+// UNIFORM: every calling lane passes the SAME op (the wave-uniform walks): the medium's chain steps, its boundary op and
+// its node id are then read once for the wave through the scalar cache instead of once per lane by vector loads that
+// sit, one behind the other, in front of every lane's boundary test.
+template <bool X, bool GENERAL = false, bool UNIFORM = false>
 PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, double time, double t_min,
                        double t_max, uint64_t pkey, uint32_t depth, double &t_out) {
+    static_assert(!(GENERAL && UNIFORM), "a boundary of several ops is walked per lane");
     const int cc = (op.kind >> 16) & 0xff;
     if (cc) {
-        apply_chain<X>(sv.xforms, op.chain_start, cc, o, d);
+        if constexpr (UNIFORM) {
+            const int start = __builtin_amdgcn_readfirstlane(op.chain_start), steps = __builtin_amdgcn_readfirstlane(cc);
+            for (int k = 0; k < steps; ++k) xform_ray<X>(load_uniform(sv.xforms + start + k), o, d);
+        } else {
+            apply_chain<X>(sv.xforms, op.chain_start, cc, o, d);
+        }
         if constexpr (!X) inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
     }
-    const DevOp &bop = sv.ops[op.skip];
+    DevOp bop_uniform;
+    if constexpr (UNIFORM) bop_uniform = load_uniform(sv.ops + __builtin_amdgcn_readfirstlane(op.skip));
+    const DevOp &bop = UNIFORM ? bop_uniform : sv.ops[op.skip];
     double t1, t2;
     int sub;
     const int32_t n_boundary = GENERAL ? (int32_t)op.d[1] : 1;
@@ -598,7 +622,10 @@ PT_DEV bool medium_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv,
     if (t1 >= t2) return false;
     double ray_length = M<X>::length(d);
     double distance_inside_boundary = (t2 - t1) * ray_length;
-    double xi = medium_draw(pkey, depth, sv.leaves[op.leaf].prim[0]);
+    int32_t medium_node;
+    if constexpr (UNIFORM) medium_node = load_uniform(&sv.leaves[__builtin_amdgcn_readfirstlane(op.leaf)].prim[0]);
+    else medium_node = sv.leaves[op.leaf].prim[0];
+    double xi = medium_draw(pkey, depth, medium_node);
     double hit_distance = -M<X>::rcp(op.d[0]) * log(xi);
     if (hit_distance < distance_inside_boundary) {
         t_out = t1 + M<X>::div(hit_distance, ray_length);
@@ -787,18 +814,6 @@ template <bool X> PT_DEV bool checker_is_odd(D3 p) {
         const bool any_zero = (ax == 0.0) | (ay == 0.0) | (az == 0.0);
         return (odd == 1.0 || odd == 3.0) && !any_zero;
     }
-}
-// Records read at a wave-uniform address come through the scalar cache into scalar registers (the constant address
-// space is how the compiler is told that it may do so; the scene's tables are never written while a kernel runs).
-// Any trivially copyable record, word by word (the compiler merges the words into wide scalar loads).
-template <class T> PT_DEV T load_uniform(const T *p) {
-    static_assert(sizeof(T) % 4 == 0, "copied word by word");
-    const uint32_t __attribute__((address_space(4))) *src = (const uint32_t __attribute__((address_space(4))) *)p;
-    T out;
-    uint32_t *dst = (uint32_t *)&out;
-#pragma unroll
-    for (size_t k = 0; k < sizeof(T) / 4; ++k) dst[k] = src[k];
-    return out;
 }
 PT_DEV pt_texture load_texture_uniform(const pt_texture *p) {
     const pt_texture __attribute__((address_space(4))) *cp = (const pt_texture __attribute__((address_space(4))) *)p;
