@@ -252,10 +252,15 @@ def test_big_tree_in_32_byte_nodes():
     scene = ptgpu.Scene.named("sphere_cloud", 1.0, param=150000)
     assert scene.accel_info()["n_nodes"] >= 32768
     primary, secondary = _rays(scene, 160, 160)
-    special = np.zeros(12, dtype=ptgpu.RAY_DTYPE)
-    special["origin"] = [(500.3, 500.1, -10.0)] * 4 + [(-10.0, 499.7, 500.2)] * 4 + [(500.0, 500.0, 500.0)] * 4
+    special = np.zeros(18, dtype=ptgpu.RAY_DTYPE)
+    # ... and rays from far outside the grid of the quantised planes, with components of wildly different sizes (the slab
+    # tests of the 32-byte nodes run in f32, widened by their rounding bound: they must not cull what the f64 tests keep)
+    special["origin"] = ([(500.3, 500.1, -10.0)] * 4 + [(-10.0, 499.7, 500.2)] * 4 + [(500.0, 500.0, 500.0)] * 4 +
+                         [(500.2, 499.9, -1.0e7), (1.0e6, 1.0e6, 1.0e6), (500.1, -100.0, 500.3), (499.0, 501.0, -3.0e4),
+                          (2.0e5, 500.0, 500.0), (500.0, 500.0, 500.0)])
     special["direction"] = [(0, 0, 1), (0, 0, 2.5), (1e-300, 0, 1), (0, 1e-9, 1), (1, 0, 0), (3, 0, 0), (1, 0, 1e-12), (1, 1, 0),
-                            (0, 0, 0), (0, -1, 0), (-1, 0, 0), (0, 0, -1)]
+                            (0, 0, 0), (0, -1, 0), (-1, 0, 0), (0, 0, -1),
+                            (0, 0, 1), (-1, -1, -1), (1e-30, 1, 1e-30), (1e-5, -1e-5, 1), (-1e8, 0, 1e-8), (1e-200, 1e-200, 1e-200)]
     batches = [primary, secondary, special]
 
     def run(steps, **tuning):
