@@ -25,11 +25,13 @@ struct PoolConsts {
 // Puts a pass's constants where the pool kernels read them. They arrive as kernel arguments, i.e. with the launch packet:
 // a copy from pageable host memory costs the host a staging copy and a wait of its own per pass, which a realtime frame
 // of a fifth of a millisecond notices.
-__global__ void k_set_pool_consts(PoolConsts value, PoolConsts *dst) {
+// The same launch clears the pass's counters (queue sizes, the chunk counter of the pool kernels).
+__global__ void k_set_pool_consts(PoolConsts value, PoolConsts *dst, uint32_t *counts, uint32_t n_counts) {
     constexpr uint32_t kWords = sizeof(PoolConsts) / sizeof(uint32_t);
     static_assert(sizeof(PoolConsts) % sizeof(uint32_t) == 0, "copied word by word");
     const uint32_t *src = (const uint32_t *)&value;
     for (uint32_t k = threadIdx.x; k < kWords; k += blockDim.x) ((uint32_t *)dst)[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < n_counts; k += blockDim.x) counts[k] = 0u;
 }
 struct PoolLds {
     LdsLeaf leaves[kLdsLeaves];

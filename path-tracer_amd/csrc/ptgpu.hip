@@ -509,7 +509,6 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     }
     auto mark = [&]() -> hipError_t { return profile ? hipEventRecord(ctx->events[ev++], st) : hipSuccess; };
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(iters + 1) * kShards * sizeof(uint32_t), st));
     const int g_all = grid_for(ctx, n);
     // One launch per pass wherever a form for it exists. Offline passes keep their paths in registers (the pool
     // kernels). Realtime frames hold 0.4 M paths after the 80 % pixel skip; through the pool they measured 16 %
@@ -527,11 +526,16 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     const bool persistent = fused && !pool;
     // the persistent kernel deals contiguous runs of tiles to its waves: one shard, entry = path id
     const QueueShape gen_shape = persistent ? QueueShape{1u, 0u, ctx->capacity} : ctx->shape;
+    // the pass's counters start at zero: cleared by the launch that sends a pool kernel its constants, where there is one
+    // (a realtime frame is four operations on the stream, and a fifth of a millisecond notices each of them)
+    const uint32_t n_counts = (iters + 1) * kShards;
+    if (!(pool || tree || xpool)) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)n_counts * sizeof(uint32_t), st));
     HIP_TRY(ctx, mark());
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
             if (hipError_t e = counted_malloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1]}, (PoolConsts *)ctx->d_pool_consts);
+        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1]}, (PoolConsts *)ctx->d_pool_consts,
+                           ctx->d_counts, n_counts);
         return hipGetLastError();
     };
     if (pool || tree || xpool) {
