@@ -419,38 +419,11 @@ __device__ __forceinline__ bool accel_box(const float *lo, const float *hi, D3 o
 }
 
 // The slab tests of a 32-byte node (AccelNodeQ). A plane is gmin + q cell, so its distance along the ray is
-// (gmin + q cell - o) inv = q (cell inv) + (gmin - o) inv: one FMA per plane with two per-ray constants per axis.
-// 1 / d is clamped to +-1e300 for them: along an axis the ray runs parallel to, an infinite factor would turn every
-// product into NaN (0 inf, inf - inf), which min / max drop, and such a ray would then be culled by nothing on that
-// axis (a ray with a zero direction by nothing at all); with the clamp the distances are +-huge with the right sign.
-struct QuantRay {
-    D3 a, b;
-};
-__device__ __forceinline__ QuantRay quant_ray(const AccelGrid &g, D3 o, D3 inv) {
-    const double big = 1.0e300;
-    const D3 i = d3(fmin(fmax(inv.x, -big), big), fmin(fmax(inv.y, -big), big), fmin(fmax(inv.z, -big), big));
-    return QuantRay{d3(g.cell[0] * i.x, g.cell[1] * i.y, g.cell[2] * i.z),
-                    d3((g.gmin[0] - o.x) * i.x, (g.gmin[1] - o.y) * i.y, (g.gmin[2] - o.z) * i.z)};
-}
-__device__ __forceinline__ void accel_boxes_q(const AccelNodeQ &n, const QuantRay &r, double t_min, double t_max, bool &h0,
-                                              bool &h1, double &t0, double &t1) {
-#define PT_Q(v, s, A, B) __builtin_fma((double)(uint32_t)(v)[s], A, B)
-    const double x00 = PT_Q(n.lo[0], 0, r.a.x, r.b.x), x01 = PT_Q(n.hi[0], 0, r.a.x, r.b.x);
-    const double y00 = PT_Q(n.lo[1], 0, r.a.y, r.b.y), y01 = PT_Q(n.hi[1], 0, r.a.y, r.b.y);
-    const double z00 = PT_Q(n.lo[2], 0, r.a.z, r.b.z), z01 = PT_Q(n.hi[2], 0, r.a.z, r.b.z);
-    const double x10 = PT_Q(n.lo[0], 1, r.a.x, r.b.x), x11 = PT_Q(n.hi[0], 1, r.a.x, r.b.x);
-    const double y10 = PT_Q(n.lo[1], 1, r.a.y, r.b.y), y11 = PT_Q(n.hi[1], 1, r.a.y, r.b.y);
-    const double z10 = PT_Q(n.lo[2], 1, r.a.z, r.b.z), z11 = PT_Q(n.hi[2], 1, r.a.z, r.b.z);
-#undef PT_Q
-    t0 = fmax(fmax(fmin(x00, x01), fmin(y00, y01)), fmax(fmin(z00, z01), t_min));
-    t1 = fmax(fmax(fmin(x10, x11), fmin(y10, y11)), fmax(fmin(z10, z11), t_min));
-    const double f0 = fmin(fmin(fmax(x00, x01), fmax(y00, y01)), fmin(fmax(z00, z01), t_max));
-    const double f1 = fmin(fmin(fmax(x10, x11), fmax(y10, y11)), fmin(fmax(z10, z11), t_max));
-    h0 = t0 <= f0;
-    h1 = t1 <= f1;
-}
-
-// The same slab tests in f32, for the kernels whose inner-node step is bound by the vector ALU (an f64 min, max, FMA or
+// (gmin + q cell - o) inv = q (cell inv) + (gmin - o) inv: one FMA per plane with two per-ray constants per axis, A and B.
+// 1 / d is clamped for them: along an axis the ray runs parallel to, an infinite factor would turn every product into
+// NaN (0 inf, inf - inf), which min / max drop, and such a ray would then be culled by nothing on that axis (a ray with
+// a zero direction by nothing at all); with the clamp the distances are +-huge with the right sign.
+// They run in f32: the inner-node step of the kernels that read these nodes is bound by the vector ALU (an f64 min, max, FMA or
 // conversion issues at half the rate of its f32 form, and there is no three-operand min / max in f64). They stay
 // conservative by construction: a plane's distance q A + B (A = cell / d, B = (gmin - o) / d) evaluated in f32 from the
 // rounded constants is off by less than E = (65536 |A| + |B|) 2^-21 on that axis (three roundings of 2^-24 relative to

@@ -291,10 +291,7 @@ template <> struct TreePoolTexLds<2> {
 // values as the general form: images are bit-identical.
 // QUANT: `nodes` holds the tree in its 32-byte form (AccelNodeQ, planes on consts->grid): two 16-byte reads per lane and
 // node visit instead of four, and the slab tests in f32, widened so that they accept whatever the f64 tests accept
-// (accel_boxes_qf); -DPT_QUANT_F32=0 builds the f64 form of the same tests for A/B runs.
-#ifndef PT_QUANT_F32
-#define PT_QUANT_F32 1
-#endif
+// (accel_boxes_qf: the f64 form of these tests measured 4 % slower on the million-sphere render).
 template <int TEX, bool MEDIA, bool RT = false, bool SPH = false, bool QUANT = false>
 __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH_WAVES : PT_SHADE_WAVES)) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
                                                                       const PoolConsts *consts, uint32_t n, uint32_t max_depth,
@@ -337,12 +334,8 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
 #else
 #define PT_TICK(acc)
 #endif
-#if PT_QUANT_F32
     QuantRayF qr{};
     float closest_up = 0.0f; // the closest hit so far as an f32 that is not below it
-#else
-    QuantRay qr{o, o};
-#endif
     auto start_ray = [&]() { // (o, d) hold a new ray
         int32_t first_node = 0;
         sp = 0;
@@ -352,12 +345,8 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
             first_node = load_uniform(&pc->start_node);            // the root, or the leaf the root holds ...
             stack[0][threadIdx.x] = load_uniform(&pc->start_push); // ... with the rest of the tree behind it
             sp = first_node < 0 ? 1 : 0;
-#if PT_QUANT_F32
             qr = quant_ray_f(load_uniform(&pc->grid), o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
             closest_up = __builtin_inff();
-#else
-            qr = quant_ray(load_uniform(&pc->grid), o, d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z)));
-#endif
         } else {
             inv = d3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
         }
@@ -470,19 +459,11 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                 bool h0, h1, first0;
                 int32_t c0, c1;
                 if constexpr (QUANT) {
-#if PT_QUANT_F32
                     const AccelNodeQWords nq = ((const AccelNodeQWords *)nodes)[node];
                     float t0, t1;
                     accel_boxes_qf(nq, qr, 0.000999f, closest_up, h0, h1, t0, t1); // (below the 0.001 of a render's rays)
                     c0 = (int32_t)nq.b.z;
                     c1 = (int32_t)nq.b.w;
-#else
-                    const AccelNodeQ nq = ((const AccelNodeQ *)nodes)[node];
-                    double t0, t1;
-                    accel_boxes_q(nq, qr, 0.001, closest, h0, h1, t0, t1);
-                    c0 = nq.child[0];
-                    c1 = nq.child[1];
-#endif
                     first0 = t0 <= t1;
                 } else {
                     double t0, t1;
@@ -522,9 +503,7 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     if (sphere_t<false>(d3(sp->c[0], sp->c[1], sp->c[2]), sp->radius, o, d, 0.001, closest, t, sub)) {
                         closest = t;
                         best = k | (sub << 28);
-#if PT_QUANT_F32
                         if constexpr (QUANT) closest_up = f32_not_below(t);
-#endif
                     }
                 } else {
                     const DevOp op = prims[k];
