@@ -246,6 +246,26 @@ def test_sphere_recipes_take_the_compact_records():
         assert int(ctx.stats().last_pass_form) == ptgpu.PT_PASS_TREE_POOL and ctx.last_pass_records() == want, name
         ctx.render(96, 64, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=1)
         assert ctx.last_pass_records() == want, name
+        if name == "random_scene":
+            # the 32-byte nodes of a small tree span the scene beside the root's leaf (the ground sphere), and rays start
+            # past the root: the same image after a refit and after a rebuild on the device, whose root holds no such
+            # leaf (both remake the nodes and the grid), and the image of the 64-byte nodes
+            ctx.reset()
+            ctx.render(96, 64, 2, 10)
+            first = ctx.readback().copy()
+            ctx.refit(0.0, 1.0)
+            ctx.render(96, 64, 2, 10)
+            assert np.array_equal(first.view(np.uint32), ctx.readback().view(np.uint32))
+            ctx.build_tree_on_device(0.0, 1.0)
+            ctx.render(96, 64, 2, 10)
+            assert ctx.last_pass_records() == want
+            assert np.array_equal(first.view(np.uint32), ctx.readback().view(np.uint32))
+            wide = ptgpu.Context(device=0, seed=0x5EED0001, max_paths_in_flight=1 << 18, flags=ptgpu.PT_CFG_WIDE_NODES)
+            wide.upload(ptgpu.Scene.named(name, 1.5, param=param))
+            wide.render(96, 64, 2, 10)
+            assert wide.last_pass_records() == ptgpu.PT_RECORDS_COMPACT_SPHERES
+            assert np.array_equal(first.view(np.uint32), wide.readback().view(np.uint32))
+            wide.close()
         ctx.close()
 
 
