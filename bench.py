@@ -82,7 +82,7 @@ def roofline_block(pt, st, model):
     memory_bound = hbm_frac is not None and fp64_frac is not None and hbm_frac > fp64_frac
     head = ({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
              "achieved_is": "bytes the L2s request from the fabric (measured, see traffic_note), per launch, over the launch's "
-                            "duration: node and primitive records as this kernel reads them, not SURVEY's per-visit model"}
+                            "duration: node and primitive records as this kernel reads them, not a per-visit byte model"}
             if memory_bound else
             {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64_frac})
     return {
