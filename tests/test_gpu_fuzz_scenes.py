@@ -2,6 +2,8 @@
 API offers (src/scene.rs:13-63, src/material.rs:80-131), built from a seed, traced on the device in both modes and by
 the CPU oracle. Small compositions are walked as a primitive list, large ones through the tree; both sizes are drawn.
 The bars are those of the recipe scenes (tests/test_gpu_parity.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -94,6 +96,11 @@ def random_composition(seed, n_prims):
 
 CASES = [(101, 6), (102, 11), (103, 17), (104, 23), (105, 24), (201, 26), (202, 40), (203, 90), (204, 300)] + \
         [(300 + k, n) for k, n in enumerate([4, 5, 7, 8, 9, 10, 12, 13, 14, 15, 16, 18, 19, 20, 21, 22, 30, 35, 50, 64, 128, 200, 500, 1000])]
+
+
+# PT_FUZZ_EXTRA=n: n more compositions (seeds 5000 ..., sizes cycling through lists and trees), for a one-off wider run
+if os.environ.get("PT_FUZZ_EXTRA"):
+    CASES = CASES + [(5000 + k, [4, 9, 17, 24, 25, 40, 90, 300, 700][k % 9]) for k in range(int(os.environ["PT_FUZZ_EXTRA"]))]
 
 
 @pytest.mark.parametrize("seed,n_prims", CASES)
