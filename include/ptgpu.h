@@ -216,8 +216,8 @@ typedef struct pt_config {
 #define PT_CFG_FAT_RECORDS 8u /* diagnostic: a scene of plain spheres alone is traced through the general primitive and
                                  leaf records instead of the compact 64-byte sphere records (same image, for A/B runs) */
 
-#define PT_CFG_WIDE_NODES 32u /* diagnostic: the one-launch pass over a big tree of plain spheres reads the 64-byte nodes
-                                 instead of their 32-byte form (same image, for A/B runs) */
+#define PT_CFG_WIDE_NODES 32u /* diagnostic: the one-launch pass over a tree of plain spheres reads the 64-byte nodes (f64
+                                 slab tests) instead of their 32-byte form (f32 slab tests); same image, for A/B runs */
 
 #define PT_CFG_COUNT_ACCEL 16u /* diagnostic, fast mode: pt_intersect* count the node records read and the primitives
                                   tested in the fast-mode tree (pt_stats.node_visits / prim_tests); the batch then runs

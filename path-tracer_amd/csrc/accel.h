@@ -25,9 +25,10 @@ struct AccelNode {
 static_assert(sizeof(AccelNode) == 64, "AccelNode must be 64 bytes");
 inline int32_t accel_leaf_ref(int32_t first, int32_t count) { return ~((first << 3) | count); }
 
-// The same node in 32 bytes, for the extend stage over big trees: the planes of both child boxes as 16-bit steps of a
-// grid over the scene's box (lower planes rounded down and upper planes up, by one step more than needed, so that the
-// decoded box always contains the f32 one). A node visit is then two 16-byte loads per lane instead of four. That
+// The same node in 32 bytes, for the extend stage over big trees and for the pass kernel of scenes of plain spheres (trees
+// of any size): the planes of both child boxes as 16-bit steps of a grid over the scene's box, or over the tree beside
+// the root's leaf when a small tree's root holds one (lower planes rounded down and upper planes up, by one step more
+// than needed, so that the decoded box always contains the f32 one). A node visit is then two 16-byte loads per lane instead of four. That
 // matters because the vector L1 serves every lane's 16 bytes of a divergent load as an access of its own and is the
 // unit that saturates on the million-sphere tree; slab tests only cull, so a slightly larger box changes no hit.
 struct AccelNodeQ {
@@ -39,7 +40,7 @@ static_assert(sizeof(AccelNodeQ) == 32, "AccelNodeQ must be 32 bytes");
 struct AccelGrid {
     double gmin[3], cell[3]; // plane = gmin + steps * cell
 };
-constexpr int32_t kAccelQuantFrom = 32768; // trees of at least this many nodes are also kept in the 32-byte form
+constexpr int32_t kAccelQuantFrom = 32768; // trees of at least this many nodes are also kept in the 32-byte form (trees over compact sphere records: always)
 
 constexpr int kAccelMaxDepth = 28; // traversal stack entries per ray (32 KiB of LDS per 256-thread workgroup)
 
