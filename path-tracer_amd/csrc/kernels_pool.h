@@ -230,10 +230,12 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(Scene
             // the per-path sum of the other forms: the first vertex is stored, later ones are added unless zero
             if (depth == 0) sum = c;
             else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+            // (a path that ends has no use for its ray any more: the next ray is taken over by every lane that shaded, which
+            // spares the copies that keeping the old one for the ended paths would need)
+            o = no;
+            d = nd;
+            beta = nbeta;
             if (alive) {
-                o = no;
-                d = nd;
-                beta = nbeta;
                 depth += 1;
             } else {
                 lx[pid] = sum.x;
@@ -581,10 +583,10 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                 }
                 if (depth == 0) sum = c; // the per-path sum of the other forms
                 else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+                o = no; // (taken over by every lane that shaded: see k_path_pool)
+                d = nd;
+                beta = nbeta;
                 if (alive) {
-                    o = no;
-                    d = nd;
-                    beta = nbeta;
                     depth += 1;
                     start_ray();
                 } else {
