@@ -312,6 +312,10 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
     constexpr int32_t kDone = INT32_MIN; // never a leaf reference
     const uint32_t lane = threadIdx.x & 63u;
     __shared__ TreePoolTexLds<TEX> T;
+    // The variant for noise / image textures runs a hundred registers over its budget: its paths' radiance sums, which a
+    // vertex touches once, live in LDS (6 KiB per workgroup) instead of six registers per lane.
+    constexpr bool kSumInLds = TEX == 2;
+    __shared__ double sum_lds[kSumInLds ? 3 : 1][kSumInLds ? kBlock : 1];
     if constexpr (TEX == 2) {
         if (sv.perlin) {
             const uint32_t *src = (const uint32_t *)sv.perlin;
@@ -581,8 +585,19 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                                                                     depth, max_depth, flags, lx, ly, lz, no, nd, nbeta, &c,
                                                                     noise_hit ? &turbulence : nullptr);
                 }
-                if (depth == 0) sum = c; // the per-path sum of the other forms
-                else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+                if constexpr (kSumInLds) { // the path's radiance sum is parked in LDS between its vertices
+                    if (depth == 0) sum = c;
+                    else {
+                        sum = d3(sum_lds[0][threadIdx.x], sum_lds[1][threadIdx.x], sum_lds[2][threadIdx.x]);
+                        if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+                    }
+                    sum_lds[0][threadIdx.x] = sum.x;
+                    sum_lds[1][threadIdx.x] = sum.y;
+                    sum_lds[2][threadIdx.x] = sum.z;
+                } else {
+                    if (depth == 0) sum = c; // the per-path sum of the other forms
+                    else if (c.x != 0.0 || c.y != 0.0 || c.z != 0.0) sum = sum + c;
+                }
                 o = no; // (taken over by every lane that shaded: see k_path_pool)
                 d = nd;
                 beta = nbeta;
