@@ -269,13 +269,15 @@ struct SceneView {
 // space is how the compiler is told that it may do so; the scene's tables are never written while a kernel runs).
 // Any trivially copyable record, word by word (the compiler merges the words into wide scalar loads).
 template <class T> PT_DEV T load_uniform(const T *p) {
-    static_assert(sizeof(T) % 4 == 0, "copied word by word");
+    static_assert(sizeof(T) % 4 == 0 && __is_trivially_copyable(T), "copied word by word");
     const uint32_t __attribute__((address_space(4))) *src = (const uint32_t __attribute__((address_space(4))) *)p;
-    T out;
-    uint32_t *dst = (uint32_t *)&out;
+    union { // (the words are read back as T through the union, not through a pointer of another type)
+        T value;
+        uint32_t words[sizeof(T) / 4];
+    } out;
 #pragma unroll
-    for (size_t k = 0; k < sizeof(T) / 4; ++k) dst[k] = src[k];
-    return out;
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) out.words[k] = src[k];
+    return out.value;
 }
 
 // ------------------------------------------------------------ transforms --
