@@ -165,8 +165,9 @@ def parse_args(argv=None):
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--scene-param", type=int, default=0, help="recipe parameter (sphere_cloud: sphere count)")
-    ap.add_argument("--paths-in-flight", type=int, default=1 << 29,
-                    help="paths per pass (228 B of device memory each: 2^29 = 122 GB of the 288 GB)")
+    ap.add_argument("--paths-in-flight", type=int, default=1 << 30,
+                    help="paths per pass (24 B of device memory each, 228 B with a pass form that keeps paths in memory: 2^30 = the "
+                         "whole default render as one pass, 26 GB)")
     ap.add_argument("--book-semantics", action="store_true", help="PT_RENDER_BOOK_SEMANTICS (Isotropic scatters as in the book)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode leg")

@@ -121,7 +121,8 @@ struct pt_ctx {
     CameraDev cam{};
 
     // path state
-    void *d_pool = nullptr; // one allocation carved into the arrays below
+    void *d_pool = nullptr;   // one allocation carved into the radiance arrays below
+    void *d_queues = nullptr; // one allocation carved into the queues and hit records (made when a form that needs them first runs)
     Queue q[2]{};
     double *d_l[3] = {nullptr, nullptr, nullptr};
     double *d_hit_t = nullptr;
@@ -285,10 +286,10 @@ int alloc_path_state(pt_ctx *ctx) {
     ctx->shape.shift = shift;
     ctx->shape.shard_cap = per_shard;
     const size_t n = ctx->capacity;
-    // 2 queues x (10 f64 + key + 2 u32) + 3 f64 radiance + hit (f64 + i32)
-    const size_t per_path = 2 * 96 + 3 * 8 + 8 + 4;
-    const size_t n_arrays = 2 + 3 + 2;
-    const size_t bytes = n * per_path + n_arrays * 256; // every array starts on a 256-byte boundary
+    // The per-path radiance (3 f64), which every pass form writes and the resolve reads: 24 bytes per path in flight. The
+    // queues and hit records of the forms that keep paths in memory (204 bytes per path) are allocated when one of those
+    // forms first runs (ensure_queues): the pool kernels, which keep their paths in registers, never touch them.
+    const size_t bytes = n * 3 * 8 + 3 * 256; // every array starts on a 256-byte boundary
     HIP_TRY(ctx, counted_malloc(&ctx->d_pool, bytes));
     char *p = (char *)ctx->d_pool;
     auto take = [&](size_t sz) {
@@ -296,19 +297,32 @@ int alloc_path_state(pt_ctx *ctx) {
         p += (sz + 255) & ~(size_t)255;
         return (void *)r;
     };
-    for (int k = 0; k < 2; ++k) {
-        Queue &q = ctx->q[k];
-        q.base = (char *)take((n / 64) * (size_t)Queue::kTileBytes); // n is a multiple of kBlock
-    }
     for (int k = 0; k < 3; ++k) ctx->d_l[k] = (double *)take(n * 8);
-    ctx->d_hit_t = (double *)take(n * 8);
-    ctx->d_hit_id = (int32_t *)take(n * 4);
     HIP_TRY(ctx, counted_malloc((void **)&ctx->d_counts, (size_t)kMaxDepthSlots * kShards * sizeof(uint32_t)));
     HIP_TRY(ctx, counted_malloc((void **)&ctx->d_stats, 2 * sizeof(unsigned long long)));
     HIP_TRY(ctx, counted_malloc((void **)&ctx->d_trav, sizeof(TraversalCounters)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_trav, 0, sizeof(TraversalCounters), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// The two path queues (96 bytes per entry each) and the hit records (f64 t, i32 id) of the pass forms that keep their paths
+// in memory, and of pt_intersect: allocated on first use, kept until the context is destroyed.
+int ensure_queues(pt_ctx *ctx) {
+    if (ctx->d_queues) return PT_OK;
+    const size_t n = ctx->capacity;
+    const size_t bytes = n * (2 * 96 + 8 + 4) + 4 * 256;
+    HIP_TRY(ctx, counted_malloc(&ctx->d_queues, bytes));
+    char *p = (char *)ctx->d_queues;
+    auto take = [&](size_t sz) {
+        char *r = p;
+        p += (sz + 255) & ~(size_t)255;
+        return (void *)r;
+    };
+    for (int k = 0; k < 2; ++k) ctx->q[k].base = (char *)take((n / 64) * (size_t)Queue::kTileBytes); // n is a multiple of kBlock
+    ctx->d_hit_t = (double *)take(n * 8);
+    ctx->d_hit_id = (int32_t *)take(n * 4);
     return PT_OK;
 }
 
@@ -529,7 +543,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // the pass's counters start at zero: cleared by the launch that sends a pool kernel its constants, where there is one
     // (a realtime frame is four operations on the stream, and a fifth of a millisecond notices each of them)
     const uint32_t n_counts = (iters + 1) * kShards;
-    if (!(pool || tree || xpool)) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)n_counts * sizeof(uint32_t), st));
+    if (!(pool || tree || xpool)) {
+        if (int rc = ensure_queues(ctx); rc != PT_OK) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)n_counts * sizeof(uint32_t), st));
+    }
     HIP_TRY(ctx, mark());
     auto send_pool_consts = [&]() -> hipError_t {
         if (!ctx->d_pool_consts)
@@ -935,7 +952,7 @@ void pt_destroy(pt_ctx *ctx) {
     if (ctx->comm && rccl_api()) (void)rccl_api()->CommDestroy(ctx->comm);
     (void)pt_present_detach(ctx);
     void *ptrs[] = {ctx->d_ops,     ctx->d_xforms,  ctx->d_leaves, ctx->d_lights, ctx->d_materials, ctx->d_textures,
-                    ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_counts, ctx->d_stats,     ctx->d_trav,
+                    ctx->d_texels,  ctx->d_perlin,  ctx->d_pool,   ctx->d_queues, ctx->d_counts, ctx->d_stats,     ctx->d_trav,
                     ctx->d_ops_list, ctx->d_ops_fused, ctx->d_accel_nodes, ctx->d_accel_prims, ctx->d_accel_parent, ctx->d_accel_levels,
                     ctx->d_accel_nodes_q, ctx->d_accel_spheres, ctx->d_image_owned, ctx->d_frames, ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_pool_consts,
                     ctx->d_stage[0], ctx->d_stage[1]};
@@ -1362,6 +1379,7 @@ int pt_intersect(pt_ctx *ctx, const pt_ray *rays, size_t n, double t_min, double
     if (n > ctx->capacity) return set_error(ctx, PT_ERR_TOO_LARGE, "ray batch larger than the paths-in-flight budget");
     int rc = ensure_stage(ctx, 0, n * sizeof(pt_ray));
     if (rc == PT_OK) rc = ensure_stage(ctx, 1, n * sizeof(pt_hit));
+    if (rc == PT_OK) rc = ensure_queues(ctx);
     if (rc != PT_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, (const pt_ray *)ctx->d_stage[0],
@@ -1412,6 +1430,7 @@ int pt_intersect_device(pt_ctx *ctx, const double *d_rays_soa, size_t n, double 
     (void)hipSetDevice(ctx->device);
     if (!device_range_ok(ctx->device, d_rays_soa, n * 7 * sizeof(double)))
         return set_error(ctx, PT_ERR_INVALID_ARG, "d_rays_soa must be device memory of this context's GPU holding 7 n doubles");
+    if (int rc = ensure_queues(ctx); rc != PT_OK) return rc;
     hipLaunchKernelGGL(k_load_rays_soa, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, d_rays_soa, (uint32_t)n,
                        ctx->q[0]);
     double ms = 0.0;
