@@ -2,7 +2,7 @@
 # Prints registers / scratch / instruction mix of the device kernels (no GPU needed): tools/kstats.sh [name filter]
 set -e
 cd "$(dirname "$0")/.."
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function ${KFLAGS} -Iinclude -Ipath-tracer_amd/csrc --cuda-device-only -S"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -mllvm -two-entry-phi-node-folding-threshold=8 ${KFLAGS} -Iinclude -Ipath-tracer_amd/csrc --cuda-device-only -S"
 /opt/rocm/bin/hipcc $FLAGS -o /tmp/ptgpu_k1.s path-tracer_amd/csrc/ptgpu.hip 2>/dev/null
 # the list path pool is a translation unit of its own (scheduler flags of its own: POOL_LIST_FLAGS of path-tracer_amd/Makefile)
 /opt/rocm/bin/hipcc $FLAGS ${POOL_LIST_FLAGS} -o /tmp/ptgpu_k2.s path-tracer_amd/csrc/pool_list.hip 2>/dev/null
