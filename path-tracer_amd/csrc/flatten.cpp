@@ -372,18 +372,23 @@ class Flattener {
                 if (int rc = emit_boundary(s_->child_index[n.list_start + k], local, guard + 1); rc != PT_OK) return rc;
             return PT_OK;
         case PT_H_BVH: {
-            if (!local.empty())
-                return fail(PT_ERR_UNSUPPORTED_SCENE, "a wrapped BVH inside a medium boundary (wrap its members instead)");
+            // A tree under wrappers (Translate / RotateY / FlipNormals above a BvhNode): its BOX ops carry the wrappers as a
+            // chain of their own, applied to the ray before the slab test, and its members inherit them in front of theirs:
+            // the reference tests every box and primitive of the subtree with the ray the wrappers hand down
+            // (src/hitable.rs:98-117,151-181, src/bvh.rs:74-99).
+            const std::vector<DevXform> bsteps = compress_chain(local);
+            if (bsteps.size() > 255) return fail(PT_ERR_UNSUPPORTED_SCENE, "transform chain longer than 255");
             DevOp box;
             std::memset(&box, 0, sizeof(box));
-            box.kind = op_pack(OP_BOX, 0, 0);
+            box.kind = op_pack(OP_BOX, 0, (int)bsteps.size());
             box.leaf = -1;
+            box.chain_start = store_chain(std::vector<DevXform>(), bsteps);
             for (int k = 0; k < 6; ++k) box.d[k] = n.f[k];
             const size_t at = boundary_ops_.size();
             boundary_ops_.push_back(box);
-            if (int rc = emit_boundary(n.child[0], std::vector<SimpleOp>(), guard + 1); rc != PT_OK) return rc;
+            if (int rc = emit_boundary(n.child[0], local, guard + 1); rc != PT_OK) return rc;
             if (n.child[1] != n.child[0])
-                if (int rc = emit_boundary(n.child[1], std::vector<SimpleOp>(), guard + 1); rc != PT_OK) return rc;
+                if (int rc = emit_boundary(n.child[1], local, guard + 1); rc != PT_OK) return rc;
             boundary_ops_[at].skip = (int32_t)boundary_ops_.size(); // relocated with the rest of the sub-stream
             return PT_OK;
         }

@@ -544,7 +544,8 @@ PT_DEV bool prim_hit(const SceneView &sv, const DevOp &op, D3 o, D3 d, D3 inv, d
 
 // Closest hit over a medium's boundary when that is more than one primitive: the threaded walk of its sub-stream
 // [first, end) of BOX and primitive ops (a HitableList is its members in order, a BvhNode its box and subtrees:
-// src/hitable.rs:51-62, src/bvh.rs:74-99), the ray already in the medium's frame.
+// src/hitable.rs:51-62, src/bvh.rs:74-99), the ray already in the medium's frame. Wrappers above a tree are the chain
+// of its BOX ops and the front of its members' chains.
 template <bool X>
 PT_DEV bool boundary_hit(const SceneView &sv, int32_t first, int32_t end, D3 o, D3 d, D3 inv, double time, double t_min,
                          double t_max, double &t_out) {
@@ -554,7 +555,16 @@ PT_DEV bool boundary_hit(const SceneView &sv, int32_t first, int32_t end, D3 o, 
     while (cur < end) {
         const DevOp *bop = &sv.ops[cur];
         if ((bop->kind & 0xff) == OP_BOX) {
-            cur = aabb_hit(bop->d, o, inv, t_min, closest) ? cur + 1 : bop->skip;
+            const int cc = (bop->kind >> 16) & 0xff;
+            bool in;
+            if (cc) { // the box of a tree under wrappers: tested with the ray those wrappers hand down
+                D3 bo = o, bd = d;
+                apply_chain<X>(sv.xforms, bop->chain_start, cc, bo, bd);
+                in = aabb_hit(bop->d, bo, d3(M<X>::rcp(bd.x), M<X>::rcp(bd.y), M<X>::rcp(bd.z)), t_min, closest);
+            } else {
+                in = aabb_hit(bop->d, o, inv, t_min, closest);
+            }
+            cur = in ? cur + 1 : bop->skip;
             continue;
         }
         double t;

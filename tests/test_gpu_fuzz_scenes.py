@@ -227,8 +227,8 @@ def test_wrapped_subtree_matches_the_oracle(any_ctx, with_medium):
 
 def nested_composition(seed, boundary):
     """Compositions the builder API allows beyond the recipes (src/hitable.rs:40-78, src/volume.rs:30-31): HitableLists
-    inside lists and under wrappers, and (boundary = "list" / "tree") a medium whose boundary is a list of two shapes or
-    a BvhNode of spheres instead of one primitive."""
+    inside lists and under wrappers, and (boundary = "list" / "tree" / "wrapped_tree") a medium whose boundary is a list of
+    two shapes, a BvhNode of spheres, or a BvhNode under wrappers instead of one primitive."""
     rng = np.random.default_rng(seed)
     s = ptgpu.Scene(seed=seed)
     U = lambda lo, hi: float(rng.uniform(lo, hi))
@@ -263,13 +263,19 @@ def nested_composition(seed, boundary):
     elif boundary == "tree":
         balls = [s.translate(s.sphere((U(-80, 80), U(-80, 80), U(-80, 80)), U(50, 90), white), (280.0, 250.0, 300.0)) for _ in range(5)]
         top.append(s.constant_medium(s.bvh(balls, 0.0, 1.0), 0.03, s.texture_constant((0.2, 0.4, 0.9))))
+    elif boundary == "wrapped_tree":  # a BvhNode under Translate and RotateY, with another wrapped BvhNode among its members
+        balls = [s.sphere((U(-80, 80), U(-80, 80), U(-80, 80)), U(50, 90), white) for _ in range(5)]
+        inner = s.translate(s.rotate_y(s.bvh(balls[3:], 0.0, 1.0), U(-40, 40)), (U(-30, 30), 0.0, U(-30, 30)))
+        tree = s.bvh(balls[:3] + [inner], 0.0, 1.0)
+        top.append(s.constant_medium(s.translate(s.rotate_y(tree, U(-40, 40)), (280.0, 250.0, 300.0)), 0.03, s.texture_constant((0.2, 0.4, 0.9))))
     s.set_root(s.list(top))
     s.set_lights([s.rect(180, 380, 180, 380, 554, 1, white)])
     s.camera = ptgpu.make_camera((278, 278, -760), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 760.0, 0.0, 1.0)
     return s
 
 
-@pytest.mark.parametrize("seed,boundary", [(401, None), (402, None), (403, "list"), (404, "list"), (405, "tree"), (406, "tree")])
+@pytest.mark.parametrize("seed,boundary", [(401, None), (402, None), (403, "list"), (404, "list"), (405, "tree"), (406, "tree"),
+                                           (407, "wrapped_tree"), (408, "wrapped_tree")])
 def test_nested_lists_and_general_medium_boundaries(any_ctx, seed, boundary):
     ctx, exact = any_ctx
     scene = nested_composition(seed, boundary)

@@ -208,12 +208,15 @@ def test_flattener_takes_nested_lists_and_rejects_what_it_cannot_walk():
     fog = s.constant_medium(s.list([s.sphere((0, 0, 0), 2, m), s.box((-1, -1, -1), (4, 1, 1), m)]), 0.1, s.texture_constant((1, 1, 1)))
     s.set_root(s.list([fog, c]))
     assert s.flatten_info()["n_ops"] == 2 and s.flatten_info()["n_leaves"] == 4
-    # what the walk of a boundary does not carry: a tree under a wrapper, a medium inside a boundary
+    # a tree under wrappers as a boundary: its BOX op carries the wrappers as a chain, its members carry them in front of theirs
     tree = s.bvh([s.sphere((0, 0, 0), 1, m), s.sphere((2, 0, 0), 1, m)])
-    for bad in (s.translate(tree, (1, 0, 0)), s.constant_medium(a, 0.2, s.texture_constant((1, 1, 1)))):
-        s.set_root(s.constant_medium(bad, 0.1, s.texture_constant((1, 1, 1))))
-        with pytest.raises(ptgpu.PtError) as e:
-            s.flatten_info()
+    s.set_root(s.constant_medium(s.translate(s.rotate_y(tree, 30.0), (1, 0, 0)), 0.1, s.texture_constant((1, 1, 1))))
+    info = s.flatten_info()
+    assert info["n_ops"] == 1 and info["n_leaves"] == 3 and info["n_xforms"] == 3
+    # what the walk of a boundary does not carry: a medium inside a boundary
+    s.set_root(s.constant_medium(s.constant_medium(a, 0.2, s.texture_constant((1, 1, 1))), 0.1, s.texture_constant((1, 1, 1))))
+    with pytest.raises(ptgpu.PtError) as e:
+        s.flatten_info()
         assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED_SCENE
 
 
