@@ -57,13 +57,16 @@ __device__ __forceinline__ DevLight wave_light(const SceneView &sv, int which, b
 // `turbulence`: the Perlin turbulence at this hit when the caller has evaluated it already (wave_turb7), else null.
 // RAD_RETURN: the vertex's radiance (every branch adds at most once) is handed back in `vertex_radiance` and nothing
 // is written (the caller keeps the path's sum).
+// `pre_sphere`: the point random_in_unit_sphere gives at this vertex and the draw count behind it (`pre_n`), when the
+// caller has made them already (wave_unit_sphere) for every Metal and Isotropic hit below the depth cap; else null.
 enum RadianceMode { RAD_ADD = 0, RAD_RETURN = 2 };
 template <bool X, int TEX, int FIRST = RAD_ADD>
 __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf &lf, D3 o, D3 d, double time, D3 beta,
                                              uint64_t pkey, uint32_t pid, uint32_t &rn, double ht, int32_t id,
                                              uint32_t depth, uint32_t max_depth, uint32_t flags, double *lx, double *ly,
                                              double *lz, D3 &no, D3 &nd, D3 &nbeta, D3 *vertex_radiance = nullptr,
-                                             const double *turbulence = nullptr) {
+                                             const double *turbulence = nullptr, const D3 *pre_sphere = nullptr,
+                                             uint32_t pre_n = 0) {
     bool alive = false;
     D3 first = d3(0.0, 0.0, 0.0);
     auto add_radiance = [&](double *ax, double *ay, double *az, uint32_t path, D3 c) {
@@ -76,6 +79,13 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
         add_radiance(lx, ly, lz, pid, beta * 0.0);
     } else {
         Rng g{pkey, rn};
+        auto unit_sphere_point = [&]() -> D3 { // src/material.rs:21-31
+            if (pre_sphere) {
+                g.n = pre_n;
+                return *pre_sphere;
+            }
+            return random_in_unit_sphere(g);
+        };
         const HitRec rec = finalize_hit<X, TEX>(sv, lf, o, d, time, ht, (id >> 28) & 7);
         PT_SHADE_TICK(1)
         const D3 emissive = emitted<X, TEX>(sv, lf, d, rec, turbulence);
@@ -125,7 +135,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 PT_SHADE_TICK(3)
             } else if (lf.mat_kind == PT_M_METAL) { // src/material.rs:230-241
                 D3 reflected = reflect<X>(M<X>::unit_vector(d), rec.n);
-                nd = reflected + lf.fuzz * random_in_unit_sphere(g);
+                nd = reflected + lf.fuzz * unit_sphere_point();
                 no = rec.p;
                 nbeta = beta * d3(lf.albedo[0], lf.albedo[1], lf.albedo[2]);
                 done = false;
@@ -138,7 +148,7 @@ __device__ __forceinline__ bool shade_vertex(const SceneView &sv, const DevLeaf 
                 const bool book = (flags & PT_RENDER_BOOK_SEMANTICS) != 0 && !lambert;
                 D3 iso_dir = d3(0.0, 0.0, 0.0);
                 if (!lambert) {
-                    const D3 sample = random_in_unit_sphere(g);
+                    const D3 sample = unit_sphere_point();
                     if (book) iso_dir = sample;
                 }
                 const double iso_pdf = book ? 0.25 * kFrac1Pi : 0.0;

@@ -968,6 +968,52 @@ PT_DEV D3 random_in_unit_sphere(Rng &g) { // src/material.rs:21-31
     }
     return p;
 }
+// random_in_unit_sphere for the lanes of a wave that `want` it, evaluated by the whole wave. A lane's draws are a pure
+// function of (key, count), so the candidates of the rejection loop can be made side by side: with m wanting lanes every
+// one of them gets C = 8, 4, 2 or 1 helper lanes (C m <= 64), helper k makes the candidate of iteration k from draws
+// 3 k + 1 ... 3 k + 3 behind the lane's count, and the lane takes the first accepted one, which is the one the serial
+// loop stops at: same draws, same arithmetic, same point, same count afterwards (n + 3 per iteration tried). Further
+// rounds of C iterations run only while some lane has found none (C = 8: one case in 400). The serial loop costs the
+// wave as many iterations as its unluckiest lane needs, four to five with ten lanes in it, each three draws long.
+// `src_tab`: 64 words of LDS of the calling wave alone. Must be called by all 64 lanes; p_out and n_out are written for
+// the wanting lanes only.
+__device__ __forceinline__ void wave_unit_sphere(bool want, uint64_t key, uint32_t n, uint32_t *src_tab, D3 &p_out,
+                                                 uint32_t &n_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long wmask = __ballot(want);
+    const uint32_t m = (uint32_t)__popcll(wmask);
+    const uint32_t rank = want ? (uint32_t)__popcll(wmask & ((1ull << lane) - 1ull)) : 0u;
+    if (want) src_tab[rank] = lane;
+    wave_lds_fence();
+    const uint32_t shift = m <= 8u ? 3u : (m <= 16u ? 2u : (m <= 32u ? 1u : 0u));
+    const uint32_t per = 1u << shift;
+    const uint32_t w = lane >> shift, k0 = lane & (per - 1u);
+    const bool helper = w < m;
+    const int src = (int)src_tab[helper ? w : 0u];
+    const uint64_t hkey = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)key, src);
+    const uint32_t hn = (uint32_t)__shfl((int)n, src);
+    bool open = want;
+    for (uint32_t base = 0;; base += per) {
+        Rng g{hkey, hn + 3u * (base + k0)};
+        const double a = g.next();
+        const double b = g.next();
+        const double c = g.next();
+        const D3 p = 2.0 * d3(a, b, c) - d3(1.0, 1.0, 1.0);
+        const bool accepted = helper && squared_length(p) < 1.0;
+        const unsigned long long amask = __ballot(accepted);
+        const uint32_t mine = (uint32_t)(amask >> (rank << shift)) & ((1u << per) - 1u); // (per <= 8)
+        const uint32_t first = mine ? (uint32_t)__builtin_ctz(mine) : 0u;
+        const int from = (int)((rank << shift) + first);
+        const double px = __shfl(p.x, from), py = __shfl(p.y, from), pz = __shfl(p.z, from);
+        if (open && mine) {
+            p_out = d3(px, py, pz);
+            n_out = n + 3u * (base + first + 1u);
+            open = false;
+        }
+        if (__ballot(open) == 0ull) break;
+    }
+    wave_lds_fence(); // the table may be written again by the next call
+}
 PT_DEV D3 random_in_unit_disk(Rng &g) { // src/camera.rs:221-228
     double a = g.next();
     double b = g.next();
