@@ -216,6 +216,31 @@ def test_pass_forms_give_the_same_image():
         assert int(st.segments) == segments, tuning
 
 
+@pytest.mark.parametrize("flags", [0, ptgpu.PT_CFG_EXACT])
+def test_unit_sphere_points_made_by_the_wave_are_the_serial_loops(flags):
+    """In the path pool of a scene with media the wave runs the rejection loop of random_in_unit_sphere together
+    (src/material.rs:21-31: helper lanes make the candidates of a lane's iterations side by side); the launch-per-bounce
+    form runs the loop lane by lane. Same draws, same points, same draw counts afterwards: the images are bit-identical,
+    in book semantics, where an Isotropic scatter goes on in the sampled direction, and in the reference's."""
+    scene = ptgpu.Scene.named("cornell_smoke", 1.0, param=1)
+    w = h = 192
+    images = {}
+    for form in (ptgpu.PT_PASS_NONE, ptgpu.PT_PASS_PER_BOUNCE):
+        ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 22, flags=flags, pass_form=form)
+        ctx.upload(scene)
+        for rflags in (ptgpu.PT_RENDER_BOOK_SEMANTICS, 0):
+            ctx.render(w, h, 16, 50, flags=rflags)
+            images[(form, rflags)] = ctx.readback()
+            if form == ptgpu.PT_PASS_NONE:
+                assert int(ctx.stats().last_pass_form) == ptgpu.PT_PASS_PATH_POOL
+        ctx.close()
+    for rflags in (ptgpu.PT_RENDER_BOOK_SEMANTICS, 0):
+        a, b = images[(ptgpu.PT_PASS_NONE, rflags)], images[(ptgpu.PT_PASS_PER_BOUNCE, rflags)]
+        assert np.array_equal(a, b, equal_nan=True)
+    book = images[(ptgpu.PT_PASS_NONE, ptgpu.PT_RENDER_BOOK_SEMANTICS)][..., :3]
+    assert np.isfinite(book).all() and book.mean() > 0.01  # the case traces smoke that scatters light on
+
+
 @pytest.mark.parametrize("name,param", [("sphere_cloud", 50000), ("final_book_two", 0)])
 def test_tree_traversal_forms_agree(name, param):
     """Fast mode walks the SAH tree either with one ray per thread or with waves that refill their free lanes from a
