@@ -352,7 +352,10 @@ def main():
         """W warm-up steps, then K steps between barriers, max over ranks: (seconds, stats, image tensor, ctx)."""
         # a rank traces every world-th row: its passes never hold more than its share of the paths
         share = W * ((H + world - 1) // world) * args.spp
-        ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=max(1 << 16, min(args.paths_in_flight, share)), flags=flags)
+        # (a profiled pass ends with a host wait for its counters: every 8th pass by default, every 64th frame of a
+        # realtime run, whose frames are otherwise issued without waiting)
+        ctx = pt.Context(device=local_rank, seed=SEED, max_paths_in_flight=max(1 << 16, min(args.paths_in_flight, share)), flags=flags,
+                         **({"profile_period": 64} if args.realtime else {}))
         ctx.upload(scene)
         # the image lives in a torch tensor (rank 0 inspects it; the torch gather moves it); the library renders into it
         image = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -408,8 +411,14 @@ def main():
             ring = ctx.present_attach(None, slots=2, width=W, height=H)  # the library's page-locked ring
         present_kind = pt.PT_PRESENT_DISPLAY8 if args.present == "ring8" else pt.PT_PRESENT_RAW
 
+        # Realtime frames are issued one behind the other without a host wait in between (PT_RENDER_NO_WAIT: the
+        # reference's main loop presents frame k while its workers trace frame k + 1, src/lib.rs:476-509); whatever reads
+        # the image through the library is ordered behind them, and the timed region ends with a device synchronisation.
+        # (The torch gather reads the bound image on torch's stream, so its frames are waited for.)
+        step_flags = rflags | (pt.PT_RENDER_NO_WAIT if (args.realtime and (world == 1 or args.gather == "capi")) else 0)
+
         def step(frame):
-            ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, flags=rflags, rows=rows)
+            ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, flags=step_flags, rows=rows)
             if world > 1:
                 gather()
             elif args.present == "readback":

@@ -249,7 +249,14 @@ typedef struct pt_render_args {
  * zero vector (439-445), so every medium scatter yields 0 or NaN. With this flag its pdf is the uniform sphere:
  * value 1/(4 pi) (the unused unit_sphere_pdf, src/material.rs:46-48), direction = the unit vector scatter() already
  * draws (349), scattering_pdf 1/(4 pi). Same number of RNG draws either way. */
-enum pt_render_flags { PT_RENDER_BOOK_SEMANTICS = 1 };
+enum pt_render_flags { PT_RENDER_BOOK_SEMANTICS = 1, PT_RENDER_NO_WAIT = 2 };
+/* PT_RENDER_NO_WAIT: pt_render / pt_render_jobs return once the work is on the context's stream instead of waiting for
+ * it. The reference's main loop hands frame k to the display while its workers already trace frame k + 1
+ * (src/lib.rs:476-509); a host that waits for every realtime frame pays a quarter of the frame's time for the round trip
+ * (1080p frames of the Cornell box: 5 100 per second with the wait, 6 000 and more without). Everything that reads the
+ * image through this library (pt_readback, pt_tonemap_*, pt_display_transform, pt_present_submit, pt_group_gather*) is
+ * ordered behind the frames already issued; a caller that reads a bound image by other means calls pt_wait first. An
+ * error of the device surfaces at the next call that waits. */
 
 typedef struct pt_stats {
     uint64_t paths;            /* paths traced since the last pt_stats_reset */
@@ -303,6 +310,8 @@ int pt_render_jobs(pt_ctx *ctx, const pt_render_args *jobs, size_t n_jobs);
 
 /* Replaces TraceSceneBatchJob::clear_buffer + zeroing the image (src/trace.rs:112-115, src/lib.rs:462-468). */
 int pt_accum_reset(pt_ctx *ctx);
+/* Blocks until everything issued on the context (renders with PT_RENDER_NO_WAIT included) has completed. */
+int pt_wait(pt_ctx *ctx);
 
 /* Replaces reading SceneOutput.buffer (src/lib.rs:496-509): copies width*height*4 floats, row 0 = bottom scanline. */
 int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats);

@@ -40,6 +40,7 @@ PT_GROUP_ID_BYTES = 128
 PT_MODE_OFFLINE = 0
 PT_MODE_REALTIME = 1
 PT_RENDER_BOOK_SEMANTICS = 1
+PT_RENDER_NO_WAIT = 2
 PT_CFG_PROFILE_STAGES = 1
 PT_CFG_COUNT_TRAVERSAL = 2
 PT_CFG_EXACT = 4
@@ -236,7 +237,7 @@ assert RAY_DTYPE.itemsize == 56 and HIT_DTYPE.itemsize == 80
 
 # Every symbol include/ptgpu.h declares.
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_scene_upload", "pt_camera_set", "pt_render", "pt_accum_reset",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_scene_upload", "pt_camera_set", "pt_render", "pt_accum_reset", "pt_wait",
     "pt_readback", "pt_image_device_ptr", "pt_image_bind", "pt_intersect", "pt_stats_get", "pt_stats_reset", "pt_last_pass_records",
     "pt_stream", "pt_intersect_device", "pt_scene_build_named", "pt_scene_free", "pt_scene_get_desc", "pt_scene_new",
     "pt_scene_texture_constant", "pt_scene_texture_checker", "pt_scene_texture_noise", "pt_scene_texture_image",
@@ -273,6 +274,7 @@ _sig("pt_camera_set", C.c_int, _vp, C.POINTER(Camera))
 _sig("pt_render", C.c_int, _vp, C.POINTER(RenderArgs))
 _sig("pt_render_jobs", C.c_int, _vp, C.POINTER(RenderArgs), C.c_size_t)
 _sig("pt_accum_reset", C.c_int, _vp)
+_sig("pt_wait", C.c_int, _vp)
 _sig("pt_readback", C.c_int, _vp, C.POINTER(C.c_float), C.c_size_t)
 _sig("pt_image_device_ptr", _vp, _vp)
 _sig("pt_image_bind", C.c_int, _vp, _vp, C.c_uint32, C.c_uint32)
@@ -567,6 +569,10 @@ class Context:
     def build_tree_on_device(self, time0, time1):
         """Builds the fast-mode tree on the device for the shutter window [time0, time1] (pt_scene_build_device)."""
         self._check(lib.pt_scene_build_device(self._h, float(time0), float(time1)), "pt_scene_build_device")
+
+    def wait(self):
+        """Blocks until everything issued on the context has completed (renders with PT_RENDER_NO_WAIT included)."""
+        self._check(lib.pt_wait(self._h), "pt_wait")
 
     def reset(self):
         self._check(lib.pt_accum_reset(self._h), "pt_accum_reset")

@@ -33,6 +33,15 @@ __global__ void k_set_pool_consts(PoolConsts value, PoolConsts *dst, uint32_t *c
     for (uint32_t k = threadIdx.x; k < kWords; k += blockDim.x) ((uint32_t *)dst)[k] = src[k];
     for (uint32_t k = threadIdx.x; k < n_counts; k += blockDim.x) counts[k] = 0u;
 }
+// Where a pool kernel reads its pass constants. An offline pass reads the copy in device memory that k_set_pool_consts
+// wrote. A realtime frame is a fifth of a millisecond, of which every operation on the stream costs some fifteen
+// microseconds: its constants travel with the launch packet itself, as the kernel's FIRST argument, and are read from the
+// kernarg segment where they are needed (the parameter is never named: named, its sixty words would sit in scalar
+// registers for the whole kernel), so the frame needs no launch of its own to deliver them.
+template <bool RT> __device__ __forceinline__ const PoolConsts *pool_consts_of(const PoolConsts *in_memory) {
+    if constexpr (RT) return (const PoolConsts *)__builtin_amdgcn_kernarg_segment_ptr();
+    else return in_memory;
+}
 struct PoolLds {
     LdsLeaf leaves[kLdsLeaves];
     // camera samples made 64 at a time by the whole wave and handed to lanes as they fall free
@@ -60,10 +69,11 @@ constexpr int pool_waves(bool exact, int fuse) {
 // of 64 ids at a time with all its lanes and collects the ids that survive, so that no sample is made for a pixel the
 // frame skips.
 template <int TEX, int FUSE, bool X = false, bool RT = false>
-__global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(SceneView sv, const PoolConsts *consts, uint32_t n,
+__global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(PoolConsts consts_by_value, SceneView sv, const PoolConsts *consts_in_memory, uint32_t n,
                                                                       uint32_t max_depth, double *lx, double *ly,
                                                                       double *lz, uint32_t *counts, uint32_t flags,
                                                                       uint32_t refill_arg, uint32_t chunk) {
+    const PoolConsts *consts = pool_consts_of<RT>(consts_in_memory);
     __shared__ PoolLds S;
     __shared__ uint32_t live[RT ? kWavesPerBlock : 1][128]; // RT: surviving path ids of the wave, not yet made into samples
     uint32_t live_n = 0;
@@ -309,10 +319,11 @@ template <> struct TreePoolTexLds<2> {
 // node visit instead of four, and the slab tests in f32, widened so that they accept whatever the f64 tests accept
 // (accel_boxes_qf: the f64 form of these tests measured 4 % slower on the million-sphere render).
 template <int TEX, bool MEDIA, bool RT = false, bool SPH = false, bool QUANT = false>
-__global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH_WAVES : PT_SHADE_WAVES)) void k_tree_pool(SceneView sv, const AccelNode *nodes, const DevOp *prims,
-                                                                      const PoolConsts *consts, uint32_t n, uint32_t max_depth,
+__global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH_WAVES : PT_SHADE_WAVES)) void k_tree_pool(PoolConsts consts_by_value, SceneView sv, const AccelNode *nodes, const DevOp *prims,
+                                                                      const PoolConsts *consts_in_memory, uint32_t n, uint32_t max_depth,
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk_arg) {
+    const PoolConsts *consts = pool_consts_of<RT>(consts_in_memory);
     static_assert(!QUANT || SPH, "the 32-byte nodes are read by the variant for plain spheres only");
     static_assert(!SPH || (TEX <= 1 && !MEDIA), "compact records: constant colours and checkers, no media");
     const uint32_t chunk = chunk_arg & 0x7fffffffu;

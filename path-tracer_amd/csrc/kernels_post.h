@@ -6,7 +6,8 @@
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const double *ly, const double *lz, double *ax,
                                                     double *ay, double *az, float *image, uint32_t *frames_per_pixel,
-                                                    PassParams pp, const uint32_t *counts, unsigned long long *stats) {
+                                                    PassParams pp, uint32_t *counts, unsigned long long *stats,
+                                                    uint32_t clear_counts) {
     uint32_t nan_pixels = 0;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < pp.cpix; p += gridDim.x * kBlock) {
         double sx = pp.first_pass ? 0.0 : ax[p];
@@ -55,6 +56,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double *lx, const doub
         const uint32_t total = (pp.max_depth + 1) * kShards;
         for (uint32_t k = threadIdx.x; k < total; k += kBlock) seg += counts[k];
         if (seg) atomicAdd(&stats[0], seg);
+        // This block is the last reader of the pass's counters. Where the next pass would otherwise need an operation of
+        // its own on the stream to start from zeros (a realtime frame through a pool kernel), the first `clear_counts`
+        // words, bounce rows and the chunk counter behind them, are cleared here (each word by the thread that read it).
+        for (uint32_t k = threadIdx.x; k < clear_counts; k += kBlock) counts[k] = 0u;
     }
 }
 

@@ -21,14 +21,15 @@ namespace {
 #include "kernels_pool.h"
 
 template <int TEX>
-void launch_tex(bool realtime, uint32_t grid, hipStream_t stream, const SceneView &sv, const PoolConsts *consts, uint32_t n,
+void launch_tex(bool realtime, uint32_t grid, hipStream_t stream, const SceneView &sv, const PoolConsts &value,
+                const PoolConsts *consts, uint32_t n,
                 uint32_t max_depth, double *lx, double *ly, double *lz, uint32_t *counts, uint32_t flags, uint32_t refill,
                 uint32_t chunk) {
     if (realtime)
-        hipLaunchKernelGGL((k_path_pool<TEX, 1, false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, consts, n, max_depth, lx,
+        hipLaunchKernelGGL((k_path_pool<TEX, 1, false, true>), dim3(grid), dim3(kBlock), 0, stream, value, sv, consts, n, max_depth, lx,
                            ly, lz, counts, flags, refill, chunk);
     else
-        hipLaunchKernelGGL((k_path_pool<TEX, 1, false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, consts, n, max_depth, lx,
+        hipLaunchKernelGGL((k_path_pool<TEX, 1, false, false>), dim3(grid), dim3(kBlock), 0, stream, value, sv, consts, n, max_depth, lx,
                            ly, lz, counts, flags, refill, chunk);
 }
 
@@ -36,13 +37,15 @@ void launch_tex(bool realtime, uint32_t grid, hipStream_t stream, const SceneVie
 
 namespace ptdev {
 
-void launch_path_pool_list(int tex, bool realtime, uint32_t grid, hipStream_t stream, const SceneView &sv, const void *consts,
+void launch_path_pool_list(int tex, bool realtime, uint32_t grid, hipStream_t stream, const SceneView &sv,
+                           const void *consts_value, const void *consts,
                            uint32_t n, uint32_t max_depth, double *lx, double *ly, double *lz, uint32_t *counts,
                            uint32_t flags, uint32_t refill, uint32_t chunk) {
     const PoolConsts *pc = (const PoolConsts *)consts;
-    if (tex == 0) launch_tex<0>(realtime, grid, stream, sv, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
-    else if (tex == 1) launch_tex<1>(realtime, grid, stream, sv, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
-    else launch_tex<2>(realtime, grid, stream, sv, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
+    const PoolConsts &value = *(const PoolConsts *)consts_value;
+    if (tex == 0) launch_tex<0>(realtime, grid, stream, sv, value, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
+    else if (tex == 1) launch_tex<1>(realtime, grid, stream, sv, value, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
+    else launch_tex<2>(realtime, grid, stream, sv, value, pc, n, max_depth, lx, ly, lz, counts, flags, refill, chunk);
 }
 
 } // namespace ptdev

@@ -128,6 +128,7 @@ struct pt_ctx {
     double *d_hit_t = nullptr;
     int32_t *d_hit_id = nullptr;
     uint32_t *d_counts = nullptr;
+    uint32_t counts_clean_words = 0; // leading words of d_counts that the last operation on the stream left at zero
     unsigned long long *d_stats = nullptr; // [0] segments, [1] nan pixels
     TraversalCounters *d_trav = nullptr;
 
@@ -547,11 +548,19 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         if (int rc = ensure_queues(ctx); rc != PT_OK) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)n_counts * sizeof(uint32_t), st));
     }
+    // A realtime frame through a pool kernel gets its constants with the launch packet (the kernel's first argument) and
+    // finds its counters cleared by the previous frame's resolve: two operations on the stream instead of three.
+    const bool counts_read_back = profile || (read_counts && !(persistent || pool || tree || xpool));
+    const bool consts_by_launch = realtime && (pool || tree) && ctx->counts_clean_words >= n_counts;
+    const uint32_t resolve_clears = (realtime && (pool || tree) && !counts_read_back) ? n_counts : 0u;
+    ctx->counts_clean_words = 0; // until this pass's resolve has run
     HIP_TRY(ctx, mark());
+    const PoolConsts pool_consts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1]};
     auto send_pool_consts = [&]() -> hipError_t {
+        if (consts_by_launch) return hipSuccess;
         if (!ctx->d_pool_consts)
             if (hipError_t e = counted_malloc(&ctx->d_pool_consts, sizeof(PoolConsts)); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, PoolConsts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1]}, (PoolConsts *)ctx->d_pool_consts,
+        hipLaunchKernelGGL(k_set_pool_consts, dim3(1), dim3(64), 0, st, pool_consts, (PoolConsts *)ctx->d_pool_consts,
                            ctx->d_counts, n_counts);
         return hipGetLastError();
     };
@@ -612,7 +621,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         HIP_TRY(ctx, mark());
         HIP_TRY(ctx, send_pool_consts());
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, v, (const PoolConsts *)ctx->d_pool_consts, n,
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, pool_consts, v, (const PoolConsts *)ctx->d_pool_consts, n,
                                pp.max_depth, ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags,
                                ctx->pool_refill | static_bit, chunk);
         };
@@ -632,7 +641,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         });
         // fast mode without media: compiled in pool_list.hip, under a scheduling strategy of its own
         if (!xpool && !media)
-            launch_path_pool_list(ctx->tex, realtime, grid, st, v, ctx->d_pool_consts, n, pp.max_depth, ctx->d_l[0], ctx->d_l[1],
+            launch_path_pool_list(ctx->tex, realtime, grid, st, v, &pool_consts, ctx->d_pool_consts, n, pp.max_depth, ctx->d_l[0], ctx->d_l[1],
                                   ctx->d_l[2], ctx->d_counts, ctx->render_flags, ctx->pool_refill | static_bit, chunk);
         HIP_TRY(ctx, mark());
     }
@@ -672,7 +681,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         HIP_TRY(ctx, mark());
         const bool media = ctx->view.has_medium != 0;
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, pool_consts, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
                                (const DevOp *)ctx->d_accel_prims, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
                                ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
         };
@@ -681,12 +690,12 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         if (spheres) {
             // plain spheres alone: the compact records stand in for the primitive ops (and the leaf table)
             auto launch_sph = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, pool_consts, ctx->view, (const AccelNode *)ctx->d_accel_nodes,
                                    (const DevOp *)ctx->d_accel_spheres, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
                                    ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
             };
             auto launch_sph_q = [&](auto kernel) { // big trees: the 32-byte nodes
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, ctx->view, (const AccelNode *)ctx->d_accel_nodes_q,
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, pool_consts, ctx->view, (const AccelNode *)ctx->d_accel_nodes_q,
                                    (const DevOp *)ctx->d_accel_spheres, (const PoolConsts *)ctx->d_pool_consts, n, pp.max_depth,
                                    ctx->d_l[0], ctx->d_l[1], ctx->d_l[2], ctx->d_counts, ctx->render_flags, tuning, chunk);
             };
@@ -740,9 +749,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     HIP_TRY(ctx, mark());
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, pp.cpix)), dim3(kBlock), 0, st, ctx->d_l[0], ctx->d_l[1],
                        ctx->d_l[2], ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_image, ctx->d_frames, pp,
-                       ctx->d_counts, ctx->d_stats);
+                       ctx->d_counts, ctx->d_stats, resolve_clears);
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
+    ctx->counts_clean_words = resolve_clears;
     ctx->stats.paths += n;
     ctx->stats.launches_raygen += (pool || tree || xpool) ? 0 : 1;
     ctx->stats.launches_extend += (fused || tree || xpool) ? 0 : iters;
@@ -1218,7 +1228,7 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
     (void)hipSetDevice(ctx->device);
     int rc = ensure_image(ctx, a->width, a->height);
     if (rc != PT_OK) return rc;
-    ctx->render_flags = a->flags;
+    ctx->render_flags = a->flags & ~(uint32_t)PT_RENDER_NO_WAIT;
 
     const uint32_t row_step = a->row_step ? a->row_step : 1u;
     if (a->row_phase >= row_step) return set_error(ctx, PT_ERR_INVALID_ARG, "row_phase must be below row_step");
@@ -1260,6 +1270,15 @@ int pt_render(pt_ctx *ctx, const pt_render_args *a) {
             if (rc != PT_OK) return rc;
         }
     }
+    if (a->flags & PT_RENDER_NO_WAIT) return PT_OK; // the caller waits when it needs the frame (pt_wait, or any reader)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_wait(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1334,6 +1353,7 @@ int pt_readback(pt_ctx *ctx, float *rgba, size_t n_floats) {
 static int extend_batch(pt_ctx *ctx, const Queue &q, uint32_t shard_cap, uint32_t *counts, double *hit_t, int32_t *hit_id,
                         size_t n, double t_min, double t_max, uint64_t medium_seed, int repeats, double *mean_ms_out) {
     const bool count = (ctx->flags & (PT_CFG_COUNT_TRAVERSAL | PT_CFG_COUNT_ACCEL)) != 0;
+    if (counts == ctx->d_counts) ctx->counts_clean_words = 0; // (a frame after this batch clears them itself)
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)counts, (int)(uint32_t)n, 1, ctx->stream));
     const int g = grid_for(ctx, n);
     ExtendArgs ea;

@@ -216,6 +216,31 @@ def test_pass_forms_give_the_same_image():
         assert int(st.segments) == segments, tuning
 
 
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "random_scene"])
+def test_frames_issued_without_waiting_are_the_same_frames(name):
+    """PT_RENDER_NO_WAIT: realtime frames are put on the context's stream one behind the other and the host waits once
+    (the reference's main loop presents frame k while its workers trace frame k + 1, src/lib.rs:476-509). A frame then
+    takes its constants from the launch packet and finds its counters cleared by the frame before it; the image after a
+    run of frames, and the segment count, are those of frames that were each waited for."""
+    scene = ptgpu.Scene.named(name, 16 / 9)
+    w, h, frames = 800, 450, 12
+    out = {}
+    for rflags in (0, ptgpu.PT_RENDER_NO_WAIT):
+        ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 22)
+        ctx.upload(scene)
+        for k in range(frames):
+            ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=k, flags=rflags)
+            if k == 5:  # a batch of rays between two frames uses the same counters
+                rays = np.zeros(64, dtype=ptgpu.RAY_DTYPE)
+                rays["direction"] = (0.0, 0.0, 1.0)
+                ctx.intersect(rays)
+        ctx.wait()
+        out[rflags] = (ctx.readback(), int(ctx.stats().segments))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[ptgpu.PT_RENDER_NO_WAIT][0], equal_nan=True)
+    assert out[0][1] == out[ptgpu.PT_RENDER_NO_WAIT][1] and out[0][1] > 0
+
+
 @pytest.mark.parametrize("flags", [0, ptgpu.PT_CFG_EXACT])
 def test_unit_sphere_points_made_by_the_wave_are_the_serial_loops(flags):
     """In the path pool of a scene with media the wave runs the rejection loop of random_in_unit_sphere together
