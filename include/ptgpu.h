@@ -253,7 +253,7 @@ enum pt_render_flags { PT_RENDER_BOOK_SEMANTICS = 1, PT_RENDER_NO_WAIT = 2 };
 /* PT_RENDER_NO_WAIT: pt_render / pt_render_jobs return once the work is on the context's stream instead of waiting for
  * it. The reference's main loop hands frame k to the display while its workers already trace frame k + 1
  * (src/lib.rs:476-509); a host that waits for every realtime frame pays a quarter of the frame's time for the round trip
- * (1080p frames of the Cornell box: 5 100 per second with the wait, 6 000 and more without). Everything that reads the
+ * (1080p frames of the Cornell box: 5 560 per second with the wait, 5 970 without). Everything that reads the
  * image through this library (pt_readback, pt_tonemap_*, pt_display_transform, pt_present_submit, pt_group_gather*) is
  * ordered behind the frames already issued; a caller that reads a bound image by other means calls pt_wait first. An
  * error of the device surfaces at the next call that waits. */
@@ -264,7 +264,8 @@ typedef struct pt_stats {
     uint64_t node_visits;      /* BVH boxes tested   (needs PT_CFG_COUNT_TRAVERSAL) */
     uint64_t prim_tests;       /* primitives tested  (needs PT_CFG_COUNT_TRAVERSAL) */
     uint64_t nan_pixels;       /* pixels whose last written colour has a NaN channel */
-    uint64_t launches_raygen, launches_extend, launches_shade, launches_resolve;
+    uint64_t launches_raygen, launches_extend, launches_shade, launches_resolve; /* (a realtime frame of one sample per
+                                * pixel through a pool kernel has no resolve launch: its paths blend their own pixels) */
     double ms_raygen, ms_extend, ms_shade, ms_resolve; /* summed HIP-event time of profiled launches (a one-launch
                                                         * pass form is timed under ms_shade) */
     uint64_t profiled_segments;/* segments processed by the profiled extend/shade launches */

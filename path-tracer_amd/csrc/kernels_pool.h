@@ -21,6 +21,12 @@ struct PoolConsts {
     // tree whose root holds a leaf (the scene-wide primitives) and the tree over the rest has its grid over the rest
     // alone; the root's own boxes, which that grid cannot hold, are not tested: both children count as hit.
     int32_t start_node, start_push; // (start_node < 0, a leaf: one stack entry)
+    // A realtime frame of one sample per pixel traced in one pass (resolve_inline != 0): every path of the frame owns its
+    // pixel, so the path that ends blends it into the image itself (blend_pixel) and no resolve launch follows.
+    float *image;
+    uint32_t *frames_per_pixel;
+    unsigned long long *stats; // [0] segments, [1] NaN pixels
+    uint32_t resolve_inline, reserved;
 };
 // Puts a pass's constants where the pool kernels read them. They arrive as kernel arguments, i.e. with the launch packet:
 // a copy from pageable host memory costs the host a staging copy and a wait of its own per pass, which a realtime frame
@@ -41,6 +47,34 @@ __global__ void k_set_pool_consts(PoolConsts value, PoolConsts *dst, uint32_t *c
 template <bool RT> __device__ __forceinline__ const PoolConsts *pool_consts_of(const PoolConsts *in_memory) {
     if constexpr (RT) return (const PoolConsts *)__builtin_amdgcn_kernarg_segment_ptr();
     else return in_memory;
+}
+// What k_resolve does for one pixel of a realtime frame of one sample (src/trace.rs:166-177), by the lane whose path ended:
+// the same operations on the same values (the pass's first and only sum starts from 0.0; a division by one sample is
+// exact), so the image is the one the resolve kernel writes. Returns 1 if the pixel is NaN afterwards.
+__device__ __forceinline__ uint32_t blend_pixel(const PoolConsts *consts, uint32_t pixel, D3 sum) {
+    const PoolConsts *pc = consts;
+    asm volatile("" : "+s"(pc)); // keeps the loads below in this block
+    float *px = load_uniform(&pc->image) + (size_t)pixel * 4;
+    uint32_t *frames = load_uniform(&pc->frames_per_pixel);
+    const double cx = 0.0 + sum.x, cy = 0.0 + sum.y, cz = 0.0 + sum.z;
+    uint32_t c = frames[pixel];
+    c += (c <= 1000u) ? 1u : 0u; // src/trace.rs:149
+    frames[pixel] = c;
+    const float weight = 1.0f / (float)c; // src/trace.rs:171-177
+    const float one_minus_weight = 1.0f - weight;
+    const float r = (float)cx * weight + px[0] * one_minus_weight;
+    const float g = (float)cy * weight + px[1] * one_minus_weight;
+    const float b = (float)cz * weight + px[2] * one_minus_weight;
+    px[0] = r;
+    px[1] = g;
+    px[2] = b;
+    return (r != r || g != g || b != b) ? 1u : 0u;
+}
+// the pass's NaN pixels, added to the statistics once per wave
+__device__ __forceinline__ void add_nan_pixels(const PoolConsts *consts, uint32_t nan_pixels) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nan_pixels += (uint32_t)__shfl_xor((int)nan_pixels, off);
+    if ((threadIdx.x & 63u) == 0 && nan_pixels) atomicAdd(load_uniform(&consts->stats) + 1, (unsigned long long)nan_pixels);
 }
 struct PoolLds {
     LdsLeaf leaves[kLdsLeaves];
@@ -74,6 +108,11 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(PoolC
                                                                       double *lz, uint32_t *counts, uint32_t flags,
                                                                       uint32_t refill_arg, uint32_t chunk) {
     const PoolConsts *consts = pool_consts_of<RT>(consts_in_memory);
+    // RT, one sample per pixel in one pass: a path carries its pixel's index instead of its path id and blends the pixel
+    // itself when it ends (needs the chunks dealt by wave index: the counters are not touched at all then)
+    bool inline_resolve = false;
+    if constexpr (RT) inline_resolve = load_uniform(&consts->resolve_inline) != 0u && (refill_arg >> 31) != 0u;
+    uint32_t nan_pixels = 0;
     __shared__ PoolLds S;
     __shared__ uint32_t live[RT ? kWavesPerBlock : 1][128]; // RT: surviving path ids of the wave, not yet made into samples
     uint32_t live_n = 0;
@@ -199,7 +238,7 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(PoolC
                     S.cam_ray[wv][6][k] = t;
                     S.cam_key[wv][k] = g.key;
                     S.cam_rn[wv][k] = g.n;
-                    S.cam_pid[wv][k] = id;
+                    S.cam_pid[wv][k] = (RT && inline_resolve) ? (uint32_t)pixel : id;
                 }
                 stash_n = (uint32_t)__popcll(made);
             }
@@ -262,9 +301,13 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(PoolC
             if (alive) {
                 depth += 1;
             } else {
-                lx[pid] = sum.x;
-                ly[pid] = sum.y;
-                lz[pid] = sum.z;
+                if (RT && inline_resolve) {
+                    nan_pixels += blend_pixel(consts, pid, sum);
+                } else {
+                    lx[pid] = sum.x;
+                    ly[pid] = sum.y;
+                    lz[pid] = sum.z;
+                }
                 has = false;
             }
         }
@@ -284,7 +327,10 @@ __global__ __launch_bounds__(kBlock, pool_waves(X, FUSE)) void k_path_pool(PoolC
 #endif
     // the pass's segment count, for the statistics: 32-bit partial sums spread over the shard slots of bounce row 0
     // (the readers add the slots up in 64 bits), so that the total may pass 2^32
-    if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments);
+    if (RT && inline_resolve) {
+        if (lane == 0 && segments) atomicAdd(load_uniform(&consts->stats), (unsigned long long)segments);
+        add_nan_pixels(consts, nan_pixels);
+    } else if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -324,6 +370,9 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                                                                       double *lx, double *ly, double *lz, uint32_t *counts,
                                                                       uint32_t flags, uint32_t tuning, uint32_t chunk_arg) {
     const PoolConsts *consts = pool_consts_of<RT>(consts_in_memory);
+    bool inline_resolve = false; // as in k_path_pool
+    if constexpr (RT) inline_resolve = load_uniform(&consts->resolve_inline) != 0u && (chunk_arg >> 31) != 0u;
+    uint32_t nan_pixels = 0;
     static_assert(!QUANT || SPH, "the 32-byte nodes are read by the variant for plain spheres only");
     static_assert(!SPH || (TEX <= 1 && !MEDIA), "compact records: constant colours and checkers, no media");
     const uint32_t chunk = chunk_arg & 0x7fffffffu;
@@ -401,9 +450,9 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
         asm volatile("" : "+s"(pc)); // keeps the loads below in this block
         const CameraDev cam = load_uniform(&pc->cam);
         const PassParams pp = load_uniform(&pc->pp);
-        pid = h;
         uint32_t i, jy, smp;
         const uint64_t pixel = pixel_of(pp, h, i, jy, smp);
+        pid = (RT && inline_resolve) ? (uint32_t)pixel : h;
         Rng g{path_key(pp.seed, pp.frame, pixel, pp.s_base + smp), 0};
         double random = g.next();
         const double u = ((double)i + random) / (double)pp.width;
@@ -630,9 +679,13 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                     depth += 1;
                     start_ray();
                 } else {
-                    lx[pid] = sum.x;
-                    ly[pid] = sum.y;
-                    lz[pid] = sum.z;
+                    if (RT && inline_resolve) {
+                        nan_pixels += blend_pixel(consts, pid, sum);
+                    } else {
+                        lx[pid] = sum.x;
+                        ly[pid] = sum.y;
+                        lz[pid] = sum.z;
+                    }
                     has = false;
                 }
             }
@@ -657,5 +710,8 @@ __global__ __launch_bounds__(kBlock, TEX == 2 ? PT_TREE_UV_WAVES : (SPH ? PT_SPH
                    (double)c[3 * k] / tm_shades, (double)c[3 * k + 1] / tm_shades, (double)c[3 * k + 2] / (double)(c[3 * k + 1] ? c[3 * k + 1] : 1));
     }
 #endif
-    if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments); // as in k_path_pool
+    if (RT && inline_resolve) { // as in k_path_pool
+        if (lane == 0 && segments) atomicAdd(load_uniform(&consts->stats), (unsigned long long)segments);
+        add_nan_pixels(consts, nan_pixels);
+    } else if (lane == 0 && segments) atomicAdd(&counts[blockIdx.x & (kShards - 1u)], segments);
 }

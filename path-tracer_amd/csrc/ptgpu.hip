@@ -551,11 +551,18 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
     // A realtime frame through a pool kernel gets its constants with the launch packet (the kernel's first argument) and
     // finds its counters cleared by the previous frame's resolve: two operations on the stream instead of three.
     const bool counts_read_back = profile || (read_counts && !(persistent || pool || tree || xpool));
-    const bool consts_by_launch = realtime && (pool || tree) && ctx->counts_clean_words >= n_counts;
-    const uint32_t resolve_clears = (realtime && (pool || tree) && !counts_read_back) ? n_counts : 0u;
+    // One sample per pixel in one pass (every frame of the reference's realtime loop): each path owns its pixel and blends
+    // it into the image itself when it ends (blend_pixel), the frame's chunks are dealt by wave index, its counters are not
+    // touched, and the frame is ONE operation on the stream. Profiled frames keep the resolve launch and its events.
+    const bool resolve_inline = realtime && (pool || tree) && !counts_read_back && pp.spp == 1 && pp.s_count == 1 &&
+                                pp.first_pass && pp.last_pass && ctx->d_frames != nullptr;
+    const bool consts_by_launch = realtime && (pool || tree) && (resolve_inline || ctx->counts_clean_words >= n_counts);
+    const uint32_t resolve_clears = (realtime && (pool || tree) && !counts_read_back && !resolve_inline) ? n_counts : 0u;
+    const uint32_t counts_clean_before = ctx->counts_clean_words;
     ctx->counts_clean_words = 0; // until this pass's resolve has run
     HIP_TRY(ctx, mark());
-    const PoolConsts pool_consts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1]};
+    const PoolConsts pool_consts{ctx->cam, pp, ctx->accel_grid_q, ctx->accel_q_start[0], ctx->accel_q_start[1],
+                                 ctx->d_image, ctx->d_frames, ctx->d_stats, resolve_inline ? 1u : 0u, 0u};
     auto send_pool_consts = [&]() -> hipError_t {
         if (consts_by_launch) return hipSuccess;
         if (!ctx->d_pool_consts)
@@ -747,17 +754,18 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         HIP_TRY(ctx, mark());
     }
     HIP_TRY(ctx, mark());
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, pp.cpix)), dim3(kBlock), 0, st, ctx->d_l[0], ctx->d_l[1],
-                       ctx->d_l[2], ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_image, ctx->d_frames, pp,
-                       ctx->d_counts, ctx->d_stats, resolve_clears);
+    if (!resolve_inline)
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, pp.cpix)), dim3(kBlock), 0, st, ctx->d_l[0], ctx->d_l[1],
+                           ctx->d_l[2], ctx->d_acc[0], ctx->d_acc[1], ctx->d_acc[2], ctx->d_image, ctx->d_frames, pp,
+                           ctx->d_counts, ctx->d_stats, resolve_clears);
     HIP_TRY(ctx, mark());
     HIP_TRY(ctx, hipGetLastError());
-    ctx->counts_clean_words = resolve_clears;
+    ctx->counts_clean_words = resolve_inline ? counts_clean_before : resolve_clears; // (such a frame leaves the counters alone)
     ctx->stats.paths += n;
     ctx->stats.launches_raygen += (pool || tree || xpool) ? 0 : 1;
     ctx->stats.launches_extend += (fused || tree || xpool) ? 0 : iters;
     ctx->stats.launches_shade += one_launch ? 1 : iters;
-    ctx->stats.launches_resolve += 1;
+    ctx->stats.launches_resolve += resolve_inline ? 0 : 1;
     ctx->stats.last_pass_form = tree ? PT_PASS_TREE_POOL : (pool || xpool) ? PT_PASS_PATH_POOL : persistent ? PT_PASS_PERSISTENT
                                 : PT_PASS_PER_BOUNCE;
     if (profile || (read_counts && !one_launch)) { // the one-launch forms size no grids from the counts

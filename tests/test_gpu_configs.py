@@ -219,14 +219,16 @@ def test_pass_forms_give_the_same_image():
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "random_scene"])
 def test_frames_issued_without_waiting_are_the_same_frames(name):
     """PT_RENDER_NO_WAIT: realtime frames are put on the context's stream one behind the other and the host waits once
-    (the reference's main loop presents frame k while its workers trace frame k + 1, src/lib.rs:476-509). A frame then
-    takes its constants from the launch packet and finds its counters cleared by the frame before it; the image after a
-    run of frames, and the segment count, are those of frames that were each waited for."""
+    (the reference's main loop presents frame k while its workers trace frame k + 1, src/lib.rs:476-509). A frame of one
+    sample per pixel through a pool kernel is one launch: its constants come with the launch packet and every path that
+    ends blends its own pixel (src/trace.rs:166-177). A context that profiles every frame keeps the constants launch
+    and the resolve launch. All three give the same image, segment count and NaN-pixel count."""
     scene = ptgpu.Scene.named(name, 16 / 9)
     w, h, frames = 800, 450, 12
     out = {}
-    for rflags in (0, ptgpu.PT_RENDER_NO_WAIT):
-        ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 22)
+    for key, cfg, rflags in (("waited", {}, 0), ("not waited", {}, ptgpu.PT_RENDER_NO_WAIT),
+                             ("resolve launch", {"flags": ptgpu.PT_CFG_PROFILE_STAGES, "profile_period": 1}, 0)):
+        ctx = ptgpu.Context(device=0, max_paths_in_flight=1 << 22, **cfg)
         ctx.upload(scene)
         for k in range(frames):
             ctx.render(w, h, 1, 10, mode=ptgpu.PT_MODE_REALTIME, frame=k, flags=rflags)
@@ -235,10 +237,13 @@ def test_frames_issued_without_waiting_are_the_same_frames(name):
                 rays["direction"] = (0.0, 0.0, 1.0)
                 ctx.intersect(rays)
         ctx.wait()
-        out[rflags] = (ctx.readback(), int(ctx.stats().segments))
+        st = ctx.stats()
+        out[key] = (ctx.readback(), int(st.segments), int(st.nan_pixels), int(st.launches_resolve))
         ctx.close()
-    assert np.array_equal(out[0][0], out[ptgpu.PT_RENDER_NO_WAIT][0], equal_nan=True)
-    assert out[0][1] == out[ptgpu.PT_RENDER_NO_WAIT][1] and out[0][1] > 0
+    for key in ("not waited", "resolve launch"):
+        assert np.array_equal(out["waited"][0], out[key][0], equal_nan=True), key
+        assert out["waited"][1:3] == out[key][1:3], key
+    assert out["waited"][1] > 0 and out["waited"][3] == 0 and out["resolve launch"][3] == frames
 
 
 @pytest.mark.parametrize("flags", [0, ptgpu.PT_CFG_EXACT])
