@@ -280,8 +280,7 @@ enum pt_pass_form {
     PT_PASS_NONE = 0,
     PT_PASS_PER_BOUNCE = 1,       /* ray generation, then an extend and a shade launch per bounce */
     PT_PASS_PERSISTENT = 3,       /* primitive-list scenes: ray generation + one trace-and-shade launch over queue tiles */
-    PT_PASS_PATH_POOL = 4,        /* primitive-list scenes, offline passes and realtime frames of 300 000 pixels and
-                                     more (as pt_tuning.pass_form: realtime frames of any size): one launch, paths stay in
+    PT_PASS_PATH_POOL = 4,        /* primitive-list scenes, offline passes and realtime frames: one launch, paths stay in
                                      registers */
     PT_PASS_TREE_POOL = 5         /* tree scenes, offline: one launch, traversal and shading inside the wave */
 };

@@ -169,7 +169,8 @@ struct pt_ctx {
     void *d_pool_consts = nullptr;
     bool exact_pool = true;       // exact mode uses the path pool too (short streams)
     bool path_pool = true;        // offline fused passes as one k_path_pool launch
-    uint32_t pool_rt_min = 300000; // realtime frames of list scenes: path ids from which the pool is used (below: the queue form)
+    uint32_t pool_rt_min = 0; // realtime frames of list scenes: path ids from which the pool is used (below: the queue form).
+                              // A frame through the pool is one launch and wins at every size (320 x 180: 13 200 against 10 200 frames/s)
     uint32_t pool_refill = 4;     // free path slots at which a wave generates new camera samples
     uint32_t pool_grid = 1;       // workgroups per resident slot
     uint32_t pool_chunk = 512;    // path ids a wave takes from the pass's counter at a time
@@ -526,12 +527,10 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
 
     const int g_all = grid_for(ctx, n);
     // One launch per pass wherever a form for it exists. Offline passes keep their paths in registers (the pool
-    // kernels). Realtime frames hold 0.4 M paths after the 80 % pixel skip; through the pool they measured 16 %
-    // slower than through the persistent queue form below (four of five generated samples are skipped), which in
-    // turn measured +53 % at 2^20 paths, +13 % at 2^22, -3 % at 2^24 against a launch per bounce.
-    // Realtime frames too (the waves evaluate the pixel skip before they make samples), from 300 000 pixels up: 800 x 450
-    // +6 % (with media +20 %), 1080p +46 %, 2160p +59 % against the queue form below; a 640 x 360 frame is all launch
-    // latency and runs 18 % faster through the queue form.
+    // kernels). Realtime frames too (the waves evaluate the pixel skip before they make samples, and a frame of one
+    // sample per pixel is one launch in all: its paths blend their own pixels), at every size: against the persistent
+    // queue form below, 320 x 180 +29 %, 640 x 360 +15 %, 1280 x 720 +51 %, with media +40 to +120 %. (The queue form
+    // itself measured +53 % at 2^20 paths, +13 % at 2^22, -3 % at 2^24 against a launch per bounce.)
     const bool pool = fused && ctx->path_pool && (!realtime || n >= ctx->pool_rt_min);
     // exact mode, short streams: the same pool around the wave-uniform walk of the reference's own tree
     const bool xpool = ctx->exact && ctx->exact_pool && ctx->path_pool && ctx->use_scan && !count && !realtime &&
@@ -611,7 +610,16 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         // the kernel's FUSE parameter: 1 / 2 without / with media; exact mode on a stream without ENTER / EXIT ops: 3 / 4
         const int fuse_id = (xpool && !frames) ? (media ? 4 : 3) : (media ? 2 : 1);
         const uint32_t resident = (uint32_t)ctx->n_cu * pool_waves(xpool, fuse_id) * ctx->pool_grid;
-        const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
+        uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
+        if (realtime) {
+            // A frame takes as long as its longest wave's chain of rounds, and a round is the shorter the fewer waves share
+            // a SIMD. A frame that would leave the waves of a full grid a handful of paths each goes to fewer, fuller
+            // waves: n / 1200 path ids per wave, between 64 and 512 (a fifth of them survive the pixel skip). 1080p keeps
+            // its 506 ids per wave; Cornell box 1280 x 720: 7 140 -> 7 820 frames/s, 800 x 450: 9 090 -> 10 200,
+            // 640 x 360: 8 000 -> 11 000, 480 x 270: 11 000 -> 13 100; beyond 512 ids per wave every size loses.
+            const uint32_t ids = std::min(512u, std::max(64u, (n / 1200u + 63u) & ~63u));
+            grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, (n + ids * kWavesPerBlock - 1) / (ids * kWavesPerBlock)));
+        }
         // a small pass is cut into at least four chunks per wave so that the waves finish together
         // (a realtime frame's ids are mostly skipped pixels: one chunk per wave, or the chunk counter, one address for the
         // whole chip, is what the frame waits for)
@@ -660,6 +668,7 @@ int run_pass(pt_ctx *ctx, const PassParams &pp, bool read_counts) {
         const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(resident, (tiles + kWavesPerBlock - 1) / kWavesPerBlock));
         const uint32_t waves = grid * kWavesPerBlock;
         const uint32_t fair = ((realtime ? (n + waves - 1u) / waves : n / (waves * 4u)) + 63u) & ~63u; // as for the path pool
+        // (fewer, fuller waves for small frames, as the path pool takes them, cost this kernel 2 to 40 %)
         uint32_t chunk = std::max(64u, realtime ? fair : std::min(ctx->pool_chunk, fair));
         if (realtime && (uint64_t)chunk * grid * kWavesPerBlock >= n) chunk |= 0x80000000u; // chunks dealt by wave index
         HIP_TRY(ctx, send_pool_consts());

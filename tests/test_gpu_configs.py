@@ -449,10 +449,10 @@ def test_pool_on_tiny_and_ragged_passes(w, h, spp):
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "two_spheres", "two_perlin_spheres", "textured_sphere",
                                   "simple_light"])
 def test_realtime_frames_of_a_list_scene_through_the_pool(name):
-    """Realtime frames of a list scene run through the path pool from 300 000 pixels up (its waves evaluate the
-    80 % pixel skip of 64 path ids at a time before they make camera samples, and take their chunks of ids by wave
-    index) and through the queue form below that. Forced either way, at a small and at a ragged size, the accumulated
-    frames are bit-identical, and they agree with the oracle."""
+    """Realtime frames of a list scene run through the path pool (its waves evaluate the 80 % pixel skip of 64 path ids
+    at a time before they make camera samples, take their chunks of ids by wave index, and blend the pixels of their
+    finished paths themselves); the queue form can be forced. Either way, at a small, a ragged and a medium size, the
+    accumulated frames are bit-identical, and they agree with the oracle."""
     scene = ptgpu.Scene.named(name, 1.0)
     for (w, h) in [(96, 64), (67, 3), (640, 400)]:
         images = {}
