@@ -415,10 +415,10 @@ def main():
         # reference's main loop presents frame k while its workers trace frame k + 1, src/lib.rs:476-509); whatever reads
         # the image through the library is ordered behind them, and the timed region ends with a device synchronisation.
         # (The torch gather reads the bound image on torch's stream, so its frames are waited for.)
-        step_flags = rflags | (pt.PT_RENDER_NO_WAIT if (args.realtime and (world == 1 or args.gather == "capi")) else 0)
-
         def step(frame):
-            ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, flags=step_flags, rows=rows)
+            # (args.gather may still fall back to "torch" at the first transfer below)
+            no_wait = pt.PT_RENDER_NO_WAIT if (args.realtime and (world == 1 or args.gather == "capi")) else 0
+            ctx.render(W, H, args.spp, args.max_depth, frame=frame, mode=mode, flags=rflags | no_wait, rows=rows)
             if world > 1:
                 gather()
             elif args.present == "readback":
